@@ -1,0 +1,89 @@
+"""ctypes loader for the C-ABI libraries built in hmse_amd/csrc (include/hmse.h).
+
+The HIP library is the product: if it is missing the import FAILS LOUDLY — there is no CPU
+fallback anywhere in this package (the CPU oracle lives in oracle/ and is test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+HIP_LIB_PATH = os.path.join(_CSRC, "libhmse_hip.so")
+CORPUS_LIB_PATH = os.path.join(_CSRC, "libhmse_corpus.so")
+
+
+class HmseCfg(C.Structure):
+    """Mirror of `hmse_cfg` (include/hmse.h)."""
+
+    _fields_ = [(n, C.c_uint32) for n in (
+        "struct_size", "min_size", "avg_size", "max_size", "norm_level", "seg_size",
+        "n_hashes", "shingle", "seed_base", "bands", "rows", "band_bits",
+        "level", "chain_depth", "layers", "delta_max_ratio_pct")]
+
+
+def build(force: bool = False) -> None:
+    """Compile every HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-s", "-j8"]
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(args)
+
+
+_hip = None
+_corpus = None
+
+_VP, _U64, _U32, _SZ = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError(
+                f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hmse_amd has no CPU fallback)")
+        L = C.CDLL(HIP_LIB_PATH)
+        cfgp = C.POINTER(HmseCfg)
+        L.hmse_cfg_default.argtypes = [cfgp]
+        L.hmse_cfg_validate.argtypes = [cfgp]
+        L.hmse_cfg_validate.restype = C.c_int
+        L.hmse_abi_version.restype = C.c_int
+        L.hmse_strerror.restype = C.c_char_p
+        L.hmse_strerror.argtypes = [C.c_int]
+        L.hmse_gear_table.argtypes = [_VP]
+        L.hmse_workspace_bytes.restype = _SZ
+        L.hmse_workspace_bytes.argtypes = [C.c_int, _U64, cfgp]
+        L.hmse_l2_cdc.restype = C.c_int
+        L.hmse_l2_cdc.argtypes = [_VP, _U64, _VP, _U32, cfgp, _VP, _U64, _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_l3_sha256.restype = C.c_int
+        L.hmse_l3_sha256.argtypes = [_VP, _U64, _VP, _U64, _VP, _VP, _SZ, _VP]
+        L.hmse_l3_dedup.restype = C.c_int
+        L.hmse_l3_dedup.argtypes = [_VP, _U64, _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_l4_minhash.restype = C.c_int
+        L.hmse_l4_minhash.argtypes = [_VP, _U64, _VP, _VP, _U64, cfgp, _VP, _VP, _SZ, _VP]
+        L.hmse_l4_lsh.restype = C.c_int
+        L.hmse_l4_lsh.argtypes = [_VP, _U64, cfgp, _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_l1_deflate.restype = C.c_int
+        L.hmse_l1_deflate.argtypes = [_VP, _U64, _VP, _VP, _VP, _U64, cfgp, _VP, _U64, _VP, _VP, _VP, _VP, _SZ, _VP]
+        _hip = L
+    return _hip
+
+
+def corpus_lib():
+    global _corpus
+    if _corpus is None:
+        if not os.path.exists(CORPUS_LIB_PATH):
+            raise ImportError(f"{CORPUS_LIB_PATH} is missing: run __graft_entry__.build()")
+        L = C.CDLL(CORPUS_LIB_PATH)
+        L.hmse_corpus_generate.restype = C.c_int
+        L.hmse_corpus_generate.argtypes = [_VP, _U64, _U64, _U32, _U64, C.c_int, C.c_int]
+        _corpus = L
+    return _corpus
+
+
+EXPORTED_SYMBOLS = (
+    "hmse_cfg_default", "hmse_cfg_validate", "hmse_abi_version", "hmse_strerror", "hmse_gear_table",
+    "hmse_workspace_bytes", "hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l4_minhash",
+    "hmse_l4_lsh", "hmse_l1_deflate")

@@ -1,0 +1,93 @@
+// abi.hip — configuration, error strings and workspace sizing of the C-ABI (include/hmse.h).
+#include "common.h"
+
+size_t hmse_l2_workspace_bytes_impl(uint64_t n, uint32_t n_seg, const hmse_cfg* cfg);
+size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t n_chunks);
+size_t hmse_l3_dedup_workspace_bytes_impl(uint64_t n_chunks);
+size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t n_chunks);
+size_t hmse_l4_lsh_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
+size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
+
+extern "C" void hmse_cfg_default(hmse_cfg* c) {
+  memset(c, 0, sizeof *c);
+  c->struct_size = (uint32_t)sizeof *c;
+  c->min_size = 2048;
+  c->avg_size = 8192;
+  c->max_size = 32768;
+  c->norm_level = 2;
+  c->seg_size = 4u << 20;
+  c->n_hashes = 128;
+  c->shingle = 4;
+  c->seed_base = 0;
+  c->bands = 4;
+  c->rows = 32;
+  c->band_bits = 16;
+  c->level = 9;
+  c->chain_depth = 0;
+  c->layers = HMSE_LAYER_L1 | HMSE_LAYER_L2 | HMSE_LAYER_L3 | HMSE_LAYER_L4;
+  c->delta_max_ratio_pct = 0;
+}
+
+static int ilog2_u32(uint32_t v) { int l = 0; while (v > 1) { v >>= 1; l++; } return l; }
+
+int hmse_cfg_validate_impl(const hmse_cfg* c) {
+  if (!c || c->struct_size != sizeof(hmse_cfg)) return HMSE_EINVAL;
+  if (c->avg_size < 256 || (c->avg_size & (c->avg_size - 1))) return HMSE_EINVAL;
+  if (c->min_size < 64 || c->min_size > c->avg_size) return HMSE_EINVAL;
+  if (c->max_size < c->avg_size || c->max_size > 32768) return HMSE_EINVAL;
+  if (c->norm_level > 4 || ilog2_u32(c->avg_size) + (int)c->norm_level > 32) return HMSE_EINVAL;
+  if (ilog2_u32(c->avg_size) - (int)c->norm_level < 1) return HMSE_EINVAL;
+  if (c->seg_size < c->max_size) return HMSE_EINVAL;
+  if (c->n_hashes != 128 || c->shingle != 4) return HMSE_EINVAL;  // device path is specialised (README.md:2575, 2586)
+  if (c->bands == 0 || c->rows == 0 || c->bands * c->rows != c->n_hashes || c->bands > 16) return HMSE_EINVAL;
+  if (c->band_bits == 0 || c->band_bits > 32) return HMSE_EINVAL;
+  if (c->level > 9) return HMSE_EINVAL;
+  if (c->chain_depth > 4096) return HMSE_EINVAL;
+  return HMSE_OK;
+}
+
+extern "C" int hmse_cfg_validate(const hmse_cfg* c) { return hmse_cfg_validate_impl(c); }
+
+void hmse_cdc_masks_hi(const hmse_cfg* cfg, uint32_t* ms_hi, uint32_t* ml_hi) {
+  const int bits = ilog2_u32(cfg->avg_size);
+  int bs = bits + (int)cfg->norm_level, bl = bits - (int)cfg->norm_level;
+  if (bl < 1) bl = 1;
+  if (bs > 32) bs = 32;
+  *ms_hi = bs >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> bs);
+  *ml_hi = ~(0xFFFFFFFFu >> bl);
+}
+
+uint32_t hmse_deflate_depth(const hmse_cfg* cfg) {
+  static const uint32_t tab[10] = {2, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  if (cfg->chain_depth) return cfg->chain_depth;
+  return tab[cfg->level > 9 ? 9 : cfg->level];
+}
+
+extern "C" int hmse_abi_version(void) { return HMSE_ABI_VERSION; }
+
+extern "C" const char* hmse_strerror(int code) {
+  switch (code) {
+    case HMSE_OK: return "ok";
+    case HMSE_EINVAL: return "invalid argument or unsupported configuration";
+    case HMSE_ENOSPC: return "buffer or workspace too small";
+    case HMSE_EHIP: return "HIP runtime error";
+    default: return "unknown error";
+  }
+}
+
+extern "C" size_t hmse_workspace_bytes(int stage, uint64_t n, const hmse_cfg* cfg) {
+  if (hmse_cfg_validate_impl(cfg) != 0) return 0;
+  switch (stage) {
+    case HMSE_STAGE_L2_CDC: {
+      // default segmentation: ceil(n / seg_size) segments (callers with finer segments pass more)
+      uint64_t n_seg = n / cfg->seg_size + 2;
+      return hmse_l2_workspace_bytes_impl(n, (uint32_t)n_seg, cfg);
+    }
+    case HMSE_STAGE_L3_SHA256: return hmse_l3_sha256_workspace_bytes_impl(n);
+    case HMSE_STAGE_L3_DEDUP: return hmse_l3_dedup_workspace_bytes_impl(n);
+    case HMSE_STAGE_L4_MINHASH: return hmse_l4_minhash_workspace_bytes_impl(n);
+    case HMSE_STAGE_L4_LSH: return hmse_l4_lsh_workspace_bytes_impl(n, cfg);
+    case HMSE_STAGE_L1_DEFLATE: return hmse_l1_deflate_workspace_bytes_impl(n, cfg);
+    default: return 0;
+  }
+}

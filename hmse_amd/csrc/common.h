@@ -1,0 +1,79 @@
+// common.h — shared device/host helpers for the gfx950 HMSE kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/hmse.h"
+
+#define HMSE_LAUNCH_CHECK()                                 \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return HMSE_EHIP;                \
+  } while (0)
+
+#define HMSE_HIP(x)                                         \
+  do {                                                      \
+    if ((x) != hipSuccess) return HMSE_EHIP;                \
+  } while (0)
+
+static inline size_t hmse_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// carve a sub-buffer out of the caller's workspace (256-B aligned pieces)
+struct WsCarver {
+  uint8_t* base;
+  size_t cap, off;
+  __host__ WsCarver(void* p, size_t c) : base((uint8_t*)p), cap(c), off(0) {}
+  template <typename T>
+  __host__ T* take(size_t count) {
+    size_t bytes = hmse_align_up(count * sizeof(T), 256);
+    T* r = (T*)(base ? base + off : nullptr);
+    off += bytes;
+    return r;
+  }
+  __host__ bool ok() const { return base != nullptr && off <= cap; }
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ uint4 load_u4_unaligned(const uint8_t* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_rotateleft32(x, r); }
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int r) { return __builtin_rotateright32(x, r); }
+
+// workgroup exclusive scan of one u32 per thread (NT threads, NT <= 1024). `red` = LDS u32[NT/64 + 1].
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* red, uint32_t* total) {
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  if (lane == 63) red[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) {
+    uint32_t c = red[w];
+    if ((uint32_t)w < wave) wbase += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return wbase + inc - v;
+}
+
+// internal cross-file declarations
+int hmse_cfg_validate_impl(const hmse_cfg* cfg);
+void hmse_cdc_masks_hi(const hmse_cfg* cfg, uint32_t* ms_hi, uint32_t* ml_hi);
+uint32_t hmse_deflate_depth(const hmse_cfg* cfg);

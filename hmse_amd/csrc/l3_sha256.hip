@@ -1,0 +1,156 @@
+// l3_sha256.hip — L3 per-chunk SHA-256 (FIPS 180-4) for gfx950.
+//
+// Replaces mbedtls_sha256(data, len, hash, 0) (README.md:2543) over every chunk.
+// The compression function is a 64-step serial chain and Merkle-Damgard chains the blocks of a
+// chunk, so the only parallel axis is ACROSS chunks: one chunk per LANE (64 chunks per wavefront,
+// "one chunk per wavefront" would idle >= 48 lanes — SURVEY.md §7).  Lanes are persistent: a lane
+// that finishes its chunk pulls the next chunk index from a device counter (wave-aggregated
+// atomic), so the 2..32 KiB length skew of FastCDC chunks does not idle a wavefront's lanes.
+// Blocks are fetched with four unaligned 16-B loads per lane (the HSA ABI enables unaligned
+// global access); byte order is fixed with v_perm (bswap).
+#include "common.h"
+
+__constant__ uint32_t kK256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+  uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    const uint32_t ch = (e & f) | (~e & g);  // -> v_bfi_b32
+    const uint32_t t1 = h + S1 + ch + kK256[i] + wi;
+    const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    const uint32_t mj = (a & b) | (c & (a | b));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+__global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restrict__ data, uint64_t n,
+                                                         const uint64_t* __restrict__ cuts, uint64_t n_chunks,
+                                                         uint8_t* __restrict__ digests, unsigned long long* counter) {
+  const uint32_t lane = lane_id();
+  // per-lane chunk state
+  uint64_t idx = 0, cur = 0, len = 0;
+  uint32_t rem = 0;       // message bytes not yet consumed
+  uint32_t phase = 3;     // 0 data blocks, 1 pad-only block pending, 3 idle (needs a chunk), 4 retired
+  uint32_t st[8];
+  for (;;) {
+    // ---- refill idle lanes (wave-aggregated fetch-add) ----
+    const uint64_t need = __ballot(phase == 3);
+    if (need) {
+      const uint32_t leader = (uint32_t)__builtin_ctzll(need);
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(need));
+      base = __shfl(base, leader, 64);
+      if (phase == 3) {
+        idx = base + (uint64_t)__builtin_popcountll(need & lanemask_lt());
+        if (idx < n_chunks) {
+          const uint64_t c0 = cuts[idx], c1 = cuts[idx + 1];
+          cur = c0; len = c1 - c0; rem = (uint32_t)len; phase = 0;
+          st[0] = 0x6a09e667; st[1] = 0xbb67ae85; st[2] = 0x3c6ef372; st[3] = 0xa54ff53a;
+          st[4] = 0x510e527f; st[5] = 0x9b05688c; st[6] = 0x1f83d9ab; st[7] = 0x5be0cd19;
+        } else {
+          phase = 4;
+        }
+      }
+    }
+    if (__ballot(phase != 4) == 0) break;
+    if (phase == 4) continue;  // retired lanes idle until the wave drains (all lanes re-converge at the ballots)
+
+    // ---- build one 64-byte block ----
+    uint32_t w[16];
+    bool last;
+    if (phase == 0) {
+      if (cur + 64 <= n) {
+        const uint4 v0 = load_u4_unaligned(data + cur), v1 = load_u4_unaligned(data + cur + 16);
+        const uint4 v2 = load_u4_unaligned(data + cur + 32), v3 = load_u4_unaligned(data + cur + 48);
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; w[11] = v2.w; w[12] = v3.x; w[13] = v3.y; w[14] = v3.z; w[15] = v3.w;
+      } else {  // within 64 bytes of the end of the buffer: bounded byte loads
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          uint32_t x = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint64_t p = cur + 4 * i + b;
+            if (p < n) x |= (uint32_t)data[p] << (8 * b);
+          }
+          w[i] = x;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32(w[i]);
+      if (rem >= 64) {
+        rem -= 64; cur += 64; last = false;
+      } else {
+        // final data block: keep `rem` message bytes, append 0x80, zero the rest
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const uint32_t lo = 4 * i;
+          if (rem <= lo) w[i] = (rem == lo) ? 0x80000000u : 0u;
+          else if (rem < lo + 4) {
+            const uint32_t k = rem - lo;  // 1..3 valid (high-order) bytes
+            w[i] = (w[i] & ~(0xFFFFFFFFu >> (8 * k))) | (0x80u << (24 - 8 * k));
+          }
+        }
+        if (rem < 56) {
+          const uint64_t bits = len * 8;
+          w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; last = true;
+        } else {
+          phase = 1; last = false;
+        }
+        rem = 0;
+      }
+    } else {  // phase 1: pad-only block carrying the length
+#pragma unroll
+      for (int i = 0; i < 14; i++) w[i] = 0;
+      const uint64_t bits = len * 8;
+      w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; last = true;
+    }
+    sha256_compress(st, w);
+    if (last) {
+      uint4 o0, o1;
+      o0.x = __builtin_bswap32(st[0]); o0.y = __builtin_bswap32(st[1]); o0.z = __builtin_bswap32(st[2]); o0.w = __builtin_bswap32(st[3]);
+      o1.x = __builtin_bswap32(st[4]); o1.y = __builtin_bswap32(st[5]); o1.z = __builtin_bswap32(st[6]); o1.w = __builtin_bswap32(st[7]);
+      uint4* dst = (uint4*)(digests + 32 * idx);
+      __builtin_memcpy(dst, &o0, 16);
+      __builtin_memcpy(dst + 1, &o1, 16);
+      phase = 3;
+    }
+  }
+}
+
+size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t) { return 256; }
+
+extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* cuts, uint64_t n_chunks, uint8_t* digests,
+                              void* ws, size_t ws_bytes, void* stream_) {
+  if (n_chunks == 0) return HMSE_OK;
+  if (!data || !cuts || !digests) return HMSE_EINVAL;
+  if (!ws || ws_bytes < 8) return HMSE_ENOSPC;
+  hipStream_t stream = (hipStream_t)stream_;
+  HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
+  // persistent grid: enough lanes to cover the chunks, at most 8 workgroups of 256 per CU (256 CUs)
+  uint64_t blocks = (n_chunks + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}

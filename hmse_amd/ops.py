@@ -1,0 +1,184 @@
+"""Stage operators L2/L3/L4/L1 over the C-ABI (include/hmse.h): tensors in, tensors out.
+
+PyTorch is plumbing here (device memory, current HIP stream); every byte of work happens in the
+hand-written gfx950 kernels of hmse_amd/csrc.  u64 arrays travel as torch.int64, u32 as torch.int32
+(same bits).  All ops run on the tensor's device and torch's current stream and raise HmseError
+on a non-zero status — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .config import IngestConfig
+
+STAGE_L2, STAGE_SHA, STAGE_DEDUP, STAGE_MINHASH, STAGE_LSH, STAGE_DEFLATE = 2, 3, 4, 5, 6, 7
+
+
+class HmseError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        msg = _lib.hip_lib().hmse_strerror(code).decode()
+        super().__init__(f"{where}: {msg} ({code})")
+        self.code = code
+
+
+def _check(rc: int, where: str) -> None:
+    if rc != 0:
+        raise HmseError(rc, where)
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise HmseError(-1, f"{name} must live in HBM (got a {t.device} tensor; hmse_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise HmseError(-1, f"{name} must be contiguous")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def workspace_bytes(stage: int, n: int, cfg: IngestConfig) -> int:
+    c = cfg.to_c()
+    return int(_lib.hip_lib().hmse_workspace_bytes(stage, n, C.byref(c)))
+
+
+def segment_offsets(n: int, seg_size: int, device) -> torch.Tensor:
+    k = max(1, -(-n // seg_size))
+    off = torch.arange(k + 1, dtype=torch.int64, device=device) * seg_size
+    return torch.clamp(off, max=n)
+
+
+def l2_cdc(data: torch.Tensor, cfg: IngestConfig, seg_off: torch.Tensor | None = None) -> torch.Tensor:
+    """FastCDC cut points. Returns int64 cuts[n_chunks+1] (cuts[0] == 0). README.md:2456-2490."""
+    _require_gpu(data, "data")
+    n = data.numel()
+    dev = data.device
+    if seg_off is None:
+        seg_off = segment_offsets(n, cfg.seg_size, dev)
+    _require_gpu(seg_off, "seg_off")
+    n_seg = seg_off.numel() - 1
+    c = cfg.to_c()
+    lib = _lib.hip_lib()
+    cap = n // cfg.min_size + n_seg + 2
+    cuts = torch.empty(cap, dtype=torch.int64, device=dev)
+    meta = torch.zeros(2, dtype=torch.int64, device=dev)  # [n_cuts, status]
+    # exact workspace for this segmentation: the generic sizing assumes ceil(n/seg_size) segments
+    ws_bytes = workspace_bytes(STAGE_L2, n, cfg) + 24 * max(0, n_seg - n // cfg.seg_size) + 4096
+    ws = _ws(ws_bytes, dev)
+    rc = lib.hmse_l2_cdc(_ptr(data), n, _ptr(seg_off), n_seg, C.byref(c), _ptr(cuts), cap, meta.data_ptr(),
+                         meta.data_ptr() + 8, ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l2_cdc")
+    n_cuts, status = (int(v) for v in meta.tolist())
+    if status & 0xFFFFFFFF:
+        raise HmseError(-2, f"hmse_l2_cdc device status {status & 0xFFFFFFFF:#x}")
+    return cuts[: n_cuts + 1]
+
+
+def l3_sha256(data: torch.Tensor, cuts: torch.Tensor) -> torch.Tensor:
+    """SHA-256 of every chunk -> uint8 [n_chunks, 32]. README.md:2543."""
+    _require_gpu(data, "data")
+    _require_gpu(cuts, "cuts")
+    n_chunks = cuts.numel() - 1
+    out = torch.empty((max(n_chunks, 0), 32), dtype=torch.uint8, device=data.device)
+    if n_chunks <= 0:
+        return out
+    ws = _ws(256, data.device)
+    rc = _lib.hip_lib().hmse_l3_sha256(_ptr(data), data.numel(), _ptr(cuts), n_chunks, _ptr(out), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l3_sha256")
+    return out
+
+
+def l3_dedup(digests: torch.Tensor):
+    """first_occ int64[n], refcount int32[n]. README.md:1288-1292."""
+    _require_gpu(digests, "digests")
+    n = digests.shape[0]
+    dev = digests.device
+    fo = torch.empty(n, dtype=torch.int64, device=dev)
+    rc_t = torch.empty(n, dtype=torch.int32, device=dev)
+    if n == 0:
+        return fo, rc_t
+    c = IngestConfig().to_c()
+    nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEDUP, n, C.byref(c)))
+    ws = _ws(nb, dev)
+    rc = _lib.hip_lib().hmse_l3_dedup(_ptr(digests), n, _ptr(fo), _ptr(rc_t), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l3_dedup")
+    return fo, rc_t
+
+
+def l4_minhash(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None) -> torch.Tensor:
+    """MinHash signatures -> int32 [n_sel, 128] (uint32 bits). README.md:2578-2598."""
+    _require_gpu(data, "data")
+    _require_gpu(cuts, "cuts")
+    if chunk_ids is not None:
+        _require_gpu(chunk_ids, "chunk_ids")
+    n_sel = (cuts.numel() - 1) if chunk_ids is None else chunk_ids.numel()
+    sig = torch.empty((max(n_sel, 0), cfg.n_hashes), dtype=torch.int32, device=data.device)
+    if n_sel <= 0:
+        return sig
+    c = cfg.to_c()
+    ws = _ws(256, data.device)
+    rc = _lib.hip_lib().hmse_l4_minhash(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), n_sel, C.byref(c), _ptr(sig),
+                                        ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l4_minhash")
+    return sig
+
+
+def l4_lsh(sig: torch.Tensor, cfg: IngestConfig):
+    """band keys int32 [n, bands], base int64 [n] (-1 = none). README.md:1375-1383, 1987-1996."""
+    _require_gpu(sig, "sig")
+    n = sig.shape[0]
+    dev = sig.device
+    keys = torch.empty((n, cfg.bands), dtype=torch.int32, device=dev)
+    base = torch.empty(n, dtype=torch.int64, device=dev)
+    if n == 0:
+        return keys, base
+    c = cfg.to_c()
+    nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_LSH, n, C.byref(c)))
+    ws = _ws(nb, dev)
+    rc = _lib.hip_lib().hmse_l4_lsh(_ptr(sig), n, C.byref(c), _ptr(keys), _ptr(base), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l4_lsh")
+    return keys, base
+
+
+def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
+               base: torch.Tensor | None = None):
+    """Per-chunk raw DEFLATE with the base chunk as dictionary.
+
+    Returns (out uint8[total], out_off int64[n_sel+1], kind uint8[n_sel]). README.md:2374-2378, 2182-2189."""
+    _require_gpu(data, "data")
+    _require_gpu(cuts, "cuts")
+    dev = data.device
+    n_sel = (cuts.numel() - 1) if chunk_ids is None else chunk_ids.numel()
+    out_off = torch.zeros(max(n_sel, 0) + 1, dtype=torch.int64, device=dev)
+    kind = torch.zeros(max(n_sel, 0), dtype=torch.uint8, device=dev)
+    if n_sel <= 0:
+        return torch.empty(0, dtype=torch.uint8, device=dev), out_off, kind
+    if chunk_ids is None:
+        raw = int((cuts[-1] - cuts[0]).item())
+    else:
+        raw = int((cuts[chunk_ids + 1] - cuts[chunk_ids]).sum().item())
+    cap = raw + 5 * n_sel + 64  # a stored block is the worst case
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = cfg.to_c()
+    nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
+    ws = _ws(nb + 2 * (raw + 8 * n_sel), dev)
+    rc = _lib.hip_lib().hmse_l1_deflate(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
+                                        _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status), ws.data_ptr(), ws.numel(),
+                                        _stream())
+    _check(rc, "hmse_l1_deflate")
+    total = int(out_off[-1].item())
+    if int(status.item()):
+        raise HmseError(-2, f"hmse_l1_deflate device status {int(status.item()):#x}")
+    return out[:total], out_off, kind

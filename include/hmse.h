@@ -1,0 +1,179 @@
+/*
+ * hmse.h — C-ABI of the MI355X-native HMSE ingest hot path (L2 -> L3 -> L4 -> L1).
+ *
+ * This is the drop-in boundary.  The reference (1Jamie/HMSE, README.md) defines no
+ * plugin/FFI interface: it has single-buffer C signatures with caller-owned output
+ * and status-int returns.  Each entry point below is the batch form
+ * of one of those signatures and cites the reference lines it replaces.
+ *
+ * Conventions (all entry points):
+ *   - every pointer marked DEVICE is a HIP device pointer on the current device;
+ *     the caller owns every buffer; the library never allocates and never syncs
+ *     (hipGraph-capturable), work is stream-ordered on `stream` (a hipStream_t
+ *     passed as void* so this header needs no HIP include);
+ *   - return 0 = HMSE_OK, <0 = HMSE_E*;  counts that are only known on the device
+ *     (n_cuts, overflow flags, stream lengths) are written to DEVICE memory;
+ *   - one stream = one engine thread (README.md:148-153, "Core 1 HMSE engine").
+ *   - integer/byte results are bit-exact against oracle/ (tests/).
+ */
+#ifndef HMSE_H
+#define HMSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMSE_ABI_VERSION 1
+
+enum {
+  HMSE_OK      = 0,
+  HMSE_EINVAL  = -1, /* bad argument / unsupported configuration              */
+  HMSE_ENOSPC  = -2, /* a caller-provided buffer or workspace is too small     */
+  HMSE_EHIP    = -3  /* a HIP runtime call failed (launch error)               */
+};
+
+/* stage ids for hmse_workspace_bytes() */
+enum {
+  HMSE_STAGE_L2_CDC     = 2,
+  HMSE_STAGE_L3_SHA256  = 3,
+  HMSE_STAGE_L3_DEDUP   = 4,
+  HMSE_STAGE_L4_MINHASH = 5,
+  HMSE_STAGE_L4_LSH     = 6,
+  HMSE_STAGE_L1_DEFLATE = 7
+};
+
+/* layer-enable mask == the reference's ablation matrix / degradation modes
+ * (VALIDATION_METHODS.md:458-464, README.md:745-770).                          */
+enum {
+  HMSE_LAYER_L1 = 1u, /* DEFLATE                */
+  HMSE_LAYER_L2 = 2u, /* content-defined chunks */
+  HMSE_LAYER_L3 = 4u, /* SHA-256 exact dedupe   */
+  HMSE_LAYER_L4 = 8u  /* MinHash/LSH + delta    */
+};
+
+/* chunk kinds in the manifest (README.md:1635-1669) */
+enum { HMSE_KIND_FULL = 0, HMSE_KIND_POINTER = 1, HMSE_KIND_DELTA = 2 };
+
+/*
+ * Configuration: mirrors the reference's compile-time constants
+ * (README.md:2354-2355, 2444-2447, 2575-2576; SURVEY.md §5 "Config / flags").
+ */
+typedef struct hmse_cfg {
+  uint32_t struct_size;  /* sizeof(hmse_cfg), ABI check                               */
+  /* L2 — FASTCDC_MIN/AVG/MAX_SIZE (README.md:2444-2446), defaults 2048/8192/32768    */
+  uint32_t min_size;     /* >= 64 (the Gear window)                                   */
+  uint32_t avg_size;     /* power of two                                              */
+  uint32_t max_size;     /* <= 32768 (uint16_t length in ChunkIndex, README.md:1267)  */
+  uint32_t norm_level;   /* FastCDC normalisation: masks use log2(avg) +/- norm bits  */
+  uint32_t seg_size;     /* resolve restarts every seg_size bytes (default 4 MiB)     */
+  /* L4 — NUM_HASHES (README.md:2575), 4-byte shingles (README.md:2584-2586)          */
+  uint32_t n_hashes;     /* 128                                                       */
+  uint32_t shingle;      /* 4                                                         */
+  uint32_t seed_base;    /* seeds are seed_base + 0..n_hashes-1 (README.md:2589-2591) */
+  uint32_t bands;        /* b = 4  (README.md:1987-1996)                              */
+  uint32_t rows;         /* r = 32, bands*rows == n_hashes                            */
+  uint32_t band_bits;    /* 16 -> 65536 buckets per band (README.md:1937-1945)        */
+  /* L1 — mz_deflateInit2(&s, 9, MZ_DEFLATED, 15, 9, ...) (README.md:2374)            */
+  uint32_t level;        /* 1..9 profile; selects chain_depth when that is 0          */
+  uint32_t chain_depth;  /* candidates examined per position (0 = from level)         */
+  uint32_t layers;       /* HMSE_LAYER_* mask                                         */
+  uint32_t delta_max_ratio_pct; /* optional gate: delta <= pct% of chunk (0 = off)    */
+} hmse_cfg;
+
+/* Fill *cfg with the defaults above. */
+void hmse_cfg_default(hmse_cfg* cfg);
+/* 0 if the configuration is supported by the device path, HMSE_EINVAL otherwise. */
+int hmse_cfg_validate(const hmse_cfg* cfg);
+
+int hmse_abi_version(void);
+const char* hmse_strerror(int code);
+
+/* The 256-entry Gear table (host copy), generated from a fixed seed. */
+void hmse_gear_table(uint64_t table[256]);
+
+/* Bytes of DEVICE workspace stage `stage` needs for an input of n bytes
+ * (L2) or n chunks (all other stages). */
+size_t hmse_workspace_bytes(int stage, uint64_t n, const hmse_cfg* cfg);
+
+/*
+ * L2 — content-defined chunking.  Replaces rabin_slide() + the cut loop of
+ * benchmark_fastcdc() (README.md:2456-2464, 2475-2490): rolling state never reset at
+ * a cut, cut iff size >= MIN && (hash hit || size >= MAX); Gear roll + two-mask
+ * normalisation; resolution restarts at every segment boundary.
+ *   data     DEVICE u8[n]
+ *   seg_off  DEVICE u64[n_seg+1], ascending, seg_off[0]=0, seg_off[n_seg]=n
+ *   cuts     DEVICE u64[cuts_cap]: receives cuts[0]=0 and then every chunk END offset
+ *   n_cuts   DEVICE u64[1]: number of chunks (cuts holds n_cuts+1 entries).
+ *            If the required count exceeds cuts_cap-1 nothing past cuts_cap is
+ *            written and n_cuts still receives the required count.
+ *   status   DEVICE u32[1]: 0 ok, bit0 = candidate workspace overflow,
+ *            bit1 = cuts_cap overflow
+ */
+int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_off, uint32_t n_seg,
+                const hmse_cfg* cfg, uint64_t* cuts, uint64_t cuts_cap, uint64_t* n_cuts,
+                uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L3 — SHA-256 of every chunk.  Replaces mbedtls_sha256(data, len, hash, 0)
+ * (README.md:2543), applied to the raw chunk.
+ *   cuts     DEVICE u64[n_chunks+1]
+ *   digests  DEVICE u8[n_chunks][32]
+ */
+int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* cuts, uint64_t n_chunks,
+                   uint8_t* digests, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L3 — exact dedupe.  Replaces the hash-index probe/insert of README.md:1288-1292,
+ * 1542-1551 on a table held whole in HBM.
+ *   first_occ DEVICE u64[n_all]: index of the earliest chunk with an equal digest
+ *   refcount  DEVICE u32[n_all]: at a first occurrence, number of chunks equal to it
+ *             (ChunkIndex.refcount, README.md:1269); 0 elsewhere
+ */
+int hmse_l3_dedup(const uint8_t* digests_all, uint64_t n_all, uint64_t* first_occ,
+                  uint32_t* refcount, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L4a — MinHash signatures.  Replaces minhash_compute(const uint8_t*, size_t,
+ * uint32_t*) (README.md:2578-2598): sig[h] = min over 4-byte shingles of
+ * MurmurHash3_x86_32(shingle, 4, seed_base + h).
+ *   chunk_ids DEVICE u64[n_sel]: chunks to sign (indices into cuts), or NULL = all
+ *   sig       DEVICE u32[n_sel][n_hashes]
+ */
+int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* cuts,
+                    const uint64_t* chunk_ids, uint64_t n_sel, const hmse_cfg* cfg,
+                    uint32_t* sig, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L4b — LSH banding (README.md:1375-1383, 1987-1996).  band key = MurmurHash3_x86_32
+ * over the band's rows*4 bytes, seed = band index (bucket = key & (2^band_bits - 1));
+ * base[i] = earliest j < i sharing a whole band with i, or -1.
+ *   band_keys DEVICE u32[n_sel][bands]
+ *   base      DEVICE i64[n_sel]  (indices into the selection)
+ */
+int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* cfg, uint32_t* band_keys,
+                int64_t* base, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L1 — per-chunk DEFLATE (RFC 1951 raw stream) with the LSH base chunk as preset
+ * dictionary.  Replaces mz_deflateInit2(&s, 9, MZ_DEFLATED, 15, 9, ...) +
+ * mz_deflate(&s, MZ_FINISH) (README.md:2374, 2378) and the delta rule of
+ * README.md:1328, 2175.
+ *   chunk_ids DEVICE u64[n_sel] or NULL = all;  base DEVICE i64[n_sel] or NULL
+ *             (index into the selection of the dictionary chunk, -1 = none)
+ *   out       DEVICE u8[out_cap]; chunk k's stream is out[out_off[k] .. out_off[k+1])
+ *   out_off   DEVICE u64[n_sel+1]
+ *   kind      DEVICE u8[n_sel]: HMSE_KIND_FULL or HMSE_KIND_DELTA
+ *   status    DEVICE u32[1]: bit0 = out_cap overflow (out_off still exact)
+ */
+int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
+                    const uint64_t* chunk_ids, const int64_t* base, uint64_t n_sel,
+                    const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
+                    uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMSE_H */

@@ -1,0 +1,150 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact (integer/byte work).  Sizes are what the oracle finishes in seconds; full-size
+properties live in test_gpu_properties.py.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import words_text
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def ocfg(orc, cfg):
+    from dataclasses import asdict
+    return orc.default_cfg(**asdict(cfg))
+
+
+CASES = [
+    ("empty", lambda: np.zeros(0, np.uint8)),
+    ("one", lambda: np.array([7], np.uint8)),
+    ("63", lambda: words_text(63)),
+    ("min-1", lambda: words_text(2047)),
+    ("min", lambda: words_text(2048)),
+    ("tile", lambda: words_text(32768)),
+    ("tile+1", lambda: words_text(32769)),
+    ("ragged", lambda: words_text(1_000_003, seed=7)),
+    ("zeros", lambda: np.zeros(300_000, np.uint8)),
+    ("ones", lambda: np.full(300_000, 255, np.uint8)),
+    ("random", lambda: np.random.Generator(np.random.PCG64(0xDEADBEEF)).integers(0, 256, 1_500_000, dtype=np.uint8)),
+    ("period64", lambda: np.tile(np.arange(64, dtype=np.uint8), 8192)),
+]
+
+
+@pytest.mark.parametrize("name,gen", CASES, ids=[c[0] for c in CASES])
+def test_l2_cuts_bit_exact(name, gen, orc, dev):
+    from hmse_amd import IngestConfig, ops
+    data = gen()
+    for cfg in (IngestConfig(), IngestConfig.reference_preset(), IngestConfig(seg_size=100_000)):
+        want = orc.cdc(data, ocfg(orc, cfg))
+        got = ops.l2_cdc(to_dev(data, dev), cfg).cpu().numpy().astype(np.uint64)
+        assert got.shape == want.shape, (name, cfg, got.shape, want.shape)
+        assert np.array_equal(got, want), (name, cfg)
+
+
+def test_l2_corpus_and_custom_segments(orc, dev, corpus_small):
+    import torch
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    d = to_dev(corpus_small, dev)
+    want = orc.cdc(corpus_small, ocfg(orc, cfg))
+    got = ops.l2_cdc(d, cfg).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, want)
+    # document-style ragged segments, including an empty one
+    n = corpus_small.size
+    seg = np.array([0, 1, 1, 70_000, 70_001, 3_000_000, n], dtype=np.uint64)
+    want = orc.cdc(corpus_small, ocfg(orc, cfg), seg)
+    got = ops.l2_cdc(d, cfg, torch.from_numpy(seg.astype(np.int64)).to(dev)).cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, want)
+
+
+def test_l3_sha256_bit_exact(orc, dev, corpus_small):
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    cuts = orc.cdc(corpus_small, ocfg(orc, cfg))
+    got = ops.l3_sha256(to_dev(corpus_small, dev), to_dev(cuts.astype(np.int64), dev)).cpu().numpy()
+    for i in range(len(cuts) - 1):
+        assert got[i].tobytes() == hashlib.sha256(corpus_small[int(cuts[i]):int(cuts[i + 1])].tobytes()).digest(), i
+
+
+def test_l3_sha256_padding_edges(dev):
+    """Every length 0..200 (all padding branches) and chunks ending exactly at the buffer end."""
+    from hmse_amd import ops
+    rng = np.random.default_rng(1)
+    lens = list(range(0, 201)) + [4095, 4096, 4097, 32768]
+    data = rng.integers(0, 256, sum(lens), dtype=np.uint8)
+    cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    got = ops.l3_sha256(to_dev(data, dev), to_dev(cuts, dev)).cpu().numpy()
+    for i, L in enumerate(lens):
+        assert got[i].tobytes() == hashlib.sha256(data[cuts[i]:cuts[i + 1]].tobytes()).digest(), L
+
+
+def test_l3_dedup_first_occurrence(orc, dev):
+    from hmse_amd import ops
+    rng = np.random.default_rng(3)
+    uniq = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    pick = rng.integers(0, 5000, 40000)
+    pick[:100] = 17  # one heavy duplicate class
+    dg = uniq[pick]
+    fo_w, rc_w = orc.dedup(dg)
+    fo, rc = ops.l3_dedup(to_dev(dg, dev))
+    assert np.array_equal(fo.cpu().numpy().astype(np.uint64), fo_w)
+    assert np.array_equal(rc.cpu().numpy().astype(np.uint32), rc_w)
+
+
+def test_l4_minhash_bit_exact(orc, dev, corpus_small):
+    from hmse_amd import IngestConfig, ops
+    for cfg in (IngestConfig(), IngestConfig(seed_base=1)):
+        data = corpus_small[: 600_000]
+        cuts = orc.cdc(data, ocfg(orc, cfg))
+        want = orc.minhash_chunks(data, cuts, ocfg(orc, cfg))
+        got = ops.l4_minhash(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want)
+
+
+def test_l4_minhash_edges_and_selection(orc, dev):
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 3, 4, 5, 64, 8191, 8195, 20000, 32768]
+    data = rng.integers(0, 256, sum(lens), dtype=np.uint8)
+    data[-32768:] = np.tile(np.frombuffer(b"abcd", np.uint8), 8192)  # one distinct-shingle-poor chunk
+    cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ids = np.array([9, 0, 3, 8, 2, 7], dtype=np.uint64)
+    want = orc.minhash_chunks(data, cuts, ocfg(orc, cfg), ids)
+    got = ops.l4_minhash(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg, to_dev(ids.astype(np.int64), dev))
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want)
+    assert (want[1] == 0xFFFFFFFF).all() and (want[4] == 0xFFFFFFFF).all()  # len < 4 (README.md:2585 underflow guard)
+
+
+def test_l4_lsh_bit_exact(orc, dev):
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    rng = np.random.default_rng(9)
+    n = 3000
+    sig = rng.integers(0, 2**32, (n, 128), dtype=np.uint64).astype(np.uint32)
+    for i in range(200, n):  # plant band matches: copy one band of an earlier signature
+        if rng.random() < 0.3:
+            j = int(rng.integers(0, i)); b = int(rng.integers(0, 4))
+            sig[i, 32 * b:32 * b + 32] = sig[j, 32 * b:32 * b + 32]
+    sig[5] = 0xFFFFFFFF; sig[77] = 0xFFFFFFFF
+    keys_w, base_w = orc.lsh(sig, ocfg(orc, cfg))
+    keys, base = ops.l4_lsh(to_dev(sig.view(np.int32), dev), cfg)
+    assert np.array_equal(keys.cpu().numpy().view(np.uint32), keys_w)
+    assert np.array_equal(base.cpu().numpy(), base_w)
+    assert (base_w >= 0).sum() > 500
