@@ -173,7 +173,7 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     c = cfg.to_c()
     nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
-    ws = _ws(nb + 2 * (raw + 8 * n_sel), dev)
+    ws = _ws(nb + (2 if base is not None else 1) * (raw + 20 * n_sel) + 256, dev)
     rc = _lib.hip_lib().hmse_l1_deflate(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
                                         _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status), ws.data_ptr(), ws.numel(),
                                         _stream())

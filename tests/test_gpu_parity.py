@@ -148,3 +148,73 @@ def test_l4_lsh_bit_exact(orc, dev):
     assert np.array_equal(keys.cpu().numpy().view(np.uint32), keys_w)
     assert np.array_equal(base.cpu().numpy(), base_w)
     assert (base_w >= 0).sum() > 500
+
+
+def _roundtrip(stream: bytes, zdict: bytes | None = None) -> bytes:
+    import zlib
+    d = zlib.decompressobj(-15, zdict=zdict) if zdict else zlib.decompressobj(-15)
+    out = d.decompress(stream) + d.flush()
+    assert d.eof and not d.unused_data
+    return out
+
+
+def test_l1_deflate_bit_exact_and_roundtrip(orc, dev, corpus_small):
+    """Streams equal the oracle's byte for byte, inflate through stock zlib, FULL/DELTA kinds agree."""
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    data = corpus_small[: 1_500_000]
+    cuts = orc.cdc(data, ocfg(orc, cfg))
+    n = len(cuts) - 1
+    base = np.full(n, -1, dtype=np.int64)
+    base[5::3] = np.arange(5, n, 3) - 4          # arbitrary earlier chunks as dictionaries
+    want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, ocfg(orc, cfg), None, base)
+    out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg, None, to_dev(base, dev))
+    out, off, kind = out.cpu().numpy(), off.cpu().numpy().astype(np.uint64), kind.cpu().numpy()
+    assert np.array_equal(off, want_off)
+    assert np.array_equal(kind, want_kind)
+    assert np.array_equal(out, want_out)
+    for k in range(n):
+        chunk = data[int(cuts[k]):int(cuts[k + 1])].tobytes()
+        zd = data[int(cuts[base[k]]):int(cuts[base[k] + 1])].tobytes() if kind[k] == 2 else None
+        assert _roundtrip(out[int(off[k]):int(off[k + 1])].tobytes(), zd) == chunk, k
+
+
+def test_l1_deflate_edges(orc, dev):
+    """Tiny chunks, incompressible (stored), one-symbol runs (huge bucket, 258-matches), near-duplicates with dict."""
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    rng = np.random.Generator(np.random.PCG64(0xDEADBEEF))
+    text = words_text(20000, seed=11)
+    variant = text.copy(); variant[rng.integers(0, 20000, 40)] = 63
+    parts = [np.array([65], np.uint8), np.frombuffer(b"ab", np.uint8), np.frombuffer(b"abc", np.uint8),
+             np.frombuffer(b"abcd", np.uint8), np.frombuffer(b"abcabcabcabc", np.uint8),
+             rng.integers(0, 256, 5000, dtype=np.uint8), np.zeros(20000, np.uint8), np.full(32768, 0x61, np.uint8),
+             text, variant, np.tile(np.arange(256, dtype=np.uint8), 64), rng.integers(0, 4, 9000, dtype=np.uint8)]
+    data = np.concatenate(parts)
+    cuts = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    base = np.full(len(parts), -1, dtype=np.int64)
+    base[9] = 8     # near-duplicate with its original as dictionary
+    base[5] = 4     # useless dictionary: must stay FULL
+    base[7] = 6
+    for lvl_cfg in (cfg, IngestConfig(level=1), IngestConfig(chain_depth=200)):
+        want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, ocfg(orc, lvl_cfg), None, base)
+        out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), lvl_cfg, None, to_dev(base, dev))
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(kind.cpu().numpy(), want_kind)
+        assert np.array_equal(out.cpu().numpy(), want_out)
+    assert want_kind[9] == 2 and want_kind[5] == 0
+
+
+def test_l1_deflate_selection(orc, dev, corpus_small):
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    data = corpus_small[: 400_000]
+    cuts = orc.cdc(data, ocfg(orc, cfg))
+    n = len(cuts) - 1
+    ids = np.array([n - 1, 0, 7, 3, 12, 5], dtype=np.uint64)
+    base = np.array([-1, -1, 1, 2, 0, -1], dtype=np.int64)   # indices into the selection
+    want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, ocfg(orc, cfg), ids, base)
+    out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg, to_dev(ids.astype(np.int64), dev), to_dev(base, dev))
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert np.array_equal(out.cpu().numpy(), want_out)
+    assert np.array_equal(kind.cpu().numpy(), want_kind)
