@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — end-to-end ingest GiB/s + CF of the L1-L4 hot path on N MI355X (one process per GPU).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the env, RCCL backend).  One JSON line on
+rank 0.  A "step" = one pass of the whole hot path (L2 FastCDC -> L3 SHA-256 + digest all-gather +
+dedupe -> L4 MinHash/LSH -> L1 dictionary DEFLATE) over this rank's shard of the corpus, inputs
+resident in HBM when the timed region starts.  Workload = BASELINE.json configs[2]/[3]: the full
+pipeline over 10 GB of Wikipedia text (wiki-synth(seed=42) unless $HMSE_CORPUS_DIR has the real
+sample), total size fixed as N grows ("strong" scaling, the way BASELINE.json's metric is worded).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel", 7: "l1_deflate_kernel"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bytes", type=float, default=10e9, help="total corpus bytes over all ranks (default 10 GB)")
+    ap.add_argument("--corpus", default="wikipedia")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--layers", default="full", help="ablation preset (hmse_amd.config.ABLATIONS)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample (0 = 4 MiB x 2 x cores, <= 128 MiB)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------ CPU leg
+def _cpu_segment(args):
+    """Oracle path over one 4 MiB segment (runs in a worker process): the reference's CPU pipeline."""
+    import hashlib
+    import zlib
+    seg, cfg_kw = args
+    from oracle import oracle as O
+    cfg = O.default_cfg(**cfg_kw)
+    cuts = O.cdc(seg, cfg)
+    digs = [hashlib.sha256(seg[int(cuts[i]):int(cuts[i + 1])]).digest() for i in range(len(cuts) - 1)]
+    sig = O.minhash_chunks(seg, cuts, cfg)
+    _, base = O.lsh(sig, cfg)
+    stored = 0
+    for i in range(len(cuts) - 1):
+        c = seg[int(cuts[i]):int(cuts[i + 1])].tobytes()
+        zd = seg[int(cuts[base[i]]):int(cuts[base[i] + 1])].tobytes() if base[i] >= 0 else None
+        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, zd) if zd else \
+            zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY)
+        stored += len(co.compress(c) + co.flush())
+    return len(digs), stored
+
+
+def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
+    """The Python zlib/hashlib + oracle CPU path on a bounded sample, all host cores."""
+    import multiprocessing as mp
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    seg = 4 << 20
+    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 32)
+    nseg = max(1, min(nseg, host.size // seg))
+    segs = [(host[i * seg:(i + 1) * seg], {}) for i in range(nseg)]
+    workers = min(cores, nseg)
+    t0 = time.time()
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_cpu_segment, segs)
+    dt = time.time() - t0
+    nbytes = nseg * seg
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": workers, "kind": "port",
+            "sample": f"first {nseg} x 4 MiB segments of the same corpus ({nbytes >> 20} MiB): oracle FastCDC + hashlib.sha256 + "
+                      f"oracle MinHash/LSH + zlib level 9 (raw, zdict=LSH base), one segment per worker",
+            "seconds": round(dt, 2), "cf_payload_zlib9": nbytes / max(1, sum(r[1] for r in res))}
+
+
+# ------------------------------------------------------------------------------------------ main
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from hmse_amd import ABLATIONS, IngestConfig, _lib, corpus, ingest, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = IngestConfig(layers=ABLATIONS[a.layers])
+    seg = cfg.seg_size
+    total = int(a.bytes) if a.scaling == "strong" else int(a.bytes) * world
+    n_seg_total = max(world, total // seg)
+    # contiguous runs of whole segments per rank
+    s0 = rank * n_seg_total // world
+    s1 = (rank + 1) * n_seg_total // world
+    n_local = (s1 - s0) * seg
+    t0 = time.time()
+    host, source = corpus.load(a.corpus, n_local, first_byte=s0 * seg)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    data = torch.from_numpy(host).to(dev)
+    torch.cuda.synchronize()
+    t_h2d = time.time() - t0
+    seg_off = ops.segment_offsets(n_local, seg, dev)
+    lib = _lib.hip_lib()
+
+    def step():
+        return ingest.ingest_shard(data, cfg, seg_off, distributed=distributed, want_stats=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        res = step()
+    lib.hmse_profile_enable(1)
+    for s in STAGE_NAMES:
+        lib.hmse_profile_read(s, None, None, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.hmse_profile_enable(0)
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-kernel durations of the timed steps (HIP events on the launch stream, inside the C-ABI)
+    kern = {}
+    for s, name in STAGE_NAMES.items():
+        ms, n = C.c_double(), C.c_uint64()
+        lib.hmse_profile_read(s, C.byref(ms), C.byref(n), 1)
+        if n.value:
+            kern[name] = {"avg_ms": ms.value / n.value, "launches": int(n.value)}
+    st = ingest.shard_stats(res)
+    # algorithmic bytes per launch: L2/L3 read every input byte once; L4a reads the unique
+    # bytes; L1 reads unique + dictionary bytes and writes the streams
+    lens = res.cuts[1:] - res.cuts[:-1]
+    dict_bytes = 0
+    if res.base is not None and res.uniq_ids.numel():
+        hb = res.base >= 0
+        dict_bytes = int(lens[res.uniq_ids[res.base[hb]]].sum().item()) if bool(hb.any()) else 0
+    alg = {"l2_hash_kernel": n_local, "l3_sha256_kernel": n_local + 32 * st["chunks"],
+           "l4_minhash_kernel": st["unique_bytes"] + 512 * st["unique"],
+           "l1_deflate_kernel": st["unique_bytes"] + dict_bytes + st["stored_bytes"]}
+    stage_roof = {}
+    for name, k in kern.items():
+        gbps = alg[name] / (k["avg_ms"] * 1e-3) / 1e9
+        stage_roof[name] = {"avg_ms": round(k["avg_ms"], 4), "alg_bytes": int(alg[name]), "GBps": round(gbps, 2),
+                            "frac_hbm": round(gbps / HBM_PEAK_GBPS, 5)}
+    dom = max(kern, key=lambda nme: kern[nme]["avg_ms"]) if kern else None
+
+    stats = [st]
+    if distributed:
+        allst = [None] * world
+        dist.all_gather_object(allst, st)
+        stats = allst
+    if rank == 0:
+        tot = ingest.merge_stats(stats)
+        value = tot["bytes"] * a.steps / dt / 2**30
+        out = {
+            "metric": "ingest_GiB_per_s", "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "u8", "data": f"synthetic: {source}" if source.startswith("wiki") else source,
+            "config": {"workload": f"{a.layers} L1-L4 ingest (FastCDC 2/8/32 KiB + SHA-256 dedupe + MinHash-128/LSH 4x32 + "
+                                   f"dictionary DEFLATE level-9 profile) over {tot['bytes'] / 1e9:.2f} GB {a.corpus}",
+                       "total_bytes": tot["bytes"], "seg_size": seg, "sharding": f"{world} x contiguous 4 MiB-segment runs",
+                       "collective": "all_gather(digests) over RCCL" if distributed else "none"},
+            "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4), "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4),
+            "lsh_hit_rate": round(tot["lsh_hit_rate"], 4), "delta_rate": round(tot["delta_rate"], 4), "chunks": tot["chunks"],
+            "frac_hbm_read_roofline": round(tot["bytes"] * a.steps / dt / 1e9 / (HBM_PEAK_GBPS * world), 6),
+            "h2d_inclusive_GiB_per_s": round(tot["bytes"] / (dt / a.steps + t_h2d) / 2**30, 3),
+            "corpus_gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 2),
+        }
+        if dom:
+            r = stage_roof[dom]
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": r["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": r["frac_hbm"], "traffic": None,
+                               "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0"}
+        out["stage_roofline"] = stage_roof
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(host, a.cpu_sample_mib)
+            except Exception as e:  # noqa: BLE001 — the baseline leg must not lose the GPU measurement
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

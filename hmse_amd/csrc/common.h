@@ -73,6 +73,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* r
   return wbase + inc - v;
 }
 
+// diagnostics: event pair around a stage's dominant kernel (see hmse_profile_enable)
+extern int g_hmse_prof;
+void hmse_prof_begin(int stage, hipStream_t s);
+void hmse_prof_end(int stage, hipStream_t s);
+#define PROF_BEGIN(stage, s) do { if (g_hmse_prof) hmse_prof_begin(stage, s); } while (0)
+#define PROF_END(stage, s) do { if (g_hmse_prof) hmse_prof_end(stage, s); } while (0)
+
 // internal cross-file declarations
 int hmse_cfg_validate_impl(const hmse_cfg* cfg);
 void hmse_cdc_masks_hi(const hmse_cfg* cfg, uint32_t* ms_hi, uint32_t* ml_hi);

@@ -695,7 +695,9 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
     attr_set = true;
   }
   uint64_t grid = 2 * n_sel < (uint64_t)N_WG ? 2 * n_sel : (uint64_t)N_WG;
+  PROF_BEGIN(HMSE_STAGE_L1_DEFLATE, stream);
   l1_deflate_kernel<<<dim3((uint32_t)grid), dim3(NT), sizeof(Shared), stream>>>(a);
+  PROF_END(HMSE_STAGE_L1_DEFLATE, stream);
   HMSE_LAUNCH_CHECK();
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status);

@@ -384,7 +384,9 @@ extern "C" int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_
   const uint64_t n_tiles = (n + L2_TILE - 1) / L2_TILE;
   if (n_tiles > 0x7FFFFFFFull) return HMSE_EINVAL;
   if (n_tiles) {
-    l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, n, ml_hi, ms_hi, w.cand, w.cand_cap, w.tinfo, w.hdr);
+    PROF_BEGIN(HMSE_STAGE_L2_CDC, stream);
+  l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, n, ml_hi, ms_hi, w.cand, w.cand_cap, w.tinfo, w.hdr);
+  PROF_END(HMSE_STAGE_L2_CDC, stream);
     HMSE_LAUNCH_CHECK();
   }
   if (n_seg) {

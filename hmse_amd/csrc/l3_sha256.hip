@@ -150,7 +150,9 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   // persistent grid: enough lanes to cover the chunks, at most 8 workgroups of 256 per CU (256 CUs)
   uint64_t blocks = (n_chunks + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  PROF_BEGIN(HMSE_STAGE_L3_SHA256, stream);
   l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws);
+  PROF_END(HMSE_STAGE_L3_SHA256, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

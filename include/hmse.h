@@ -173,6 +173,15 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
                     uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/*
+ * Diagnostics (bench.py's roofline leg): when enabled, every entry point brackets its DOMINANT
+ * kernel launch with a HIP event pair on the caller's stream.  hmse_profile_read() waits for the
+ * recorded events (a host sync — never call it inside a capture), adds their durations to the
+ * stage's running total and returns it.  Off by default; not part of the data path.
+ */
+void hmse_profile_enable(int on);
+int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset);
+
 #ifdef __cplusplus
 }
 #endif
