@@ -44,6 +44,11 @@ def hip_lib():
             raise ImportError(
                 f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hmse_amd has no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Import torch FIRST so that the C-ABI library binds to the runtime that owns the
+        # tensors and streams it will be handed; loaded the other way round, the process ends up with
+        # two runtimes and every launch fails with a HIP error.
+        import torch  # noqa: F401
         L = C.CDLL(HIP_LIB_PATH)
         cfgp = C.POINTER(HmseCfg)
         L.hmse_cfg_default.argtypes = [cfgp]

@@ -669,6 +669,7 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
   if (!out_off || !status) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   HMSE_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), stream));
   if (n_sel == 0) { HMSE_HIP(hipMemsetAsync(out_off, 0, sizeof(uint64_t), stream)); return HMSE_OK; }
   if (!data || !cuts || !out || !kind) return HMSE_EINVAL;

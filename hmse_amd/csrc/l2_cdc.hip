@@ -376,6 +376,7 @@ extern "C" int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_
   if (n > 0 && !data) return HMSE_EINVAL;
   if (n_seg == 0 && n > 0) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   L2Ws w = l2_carve(ws, ws_bytes, n, n_seg, cfg);
   if (!w.ok) return HMSE_ENOSPC;
   HMSE_HIP(hipMemsetAsync(w.hdr, 0, sizeof(L2Header), stream));

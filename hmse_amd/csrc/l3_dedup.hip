@@ -91,6 +91,7 @@ extern "C" int hmse_l3_dedup(const uint8_t* digests_all, uint64_t n_all, uint64_
   const uint32_t slots = table_slots(n_all);
   if (!ws || ws_bytes < (size_t)slots * 4) return HMSE_ENOSPC;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   uint32_t* table = (uint32_t*)ws;
   HMSE_HIP(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, stream));
   if (refcount) HMSE_HIP(hipMemsetAsync(refcount, 0, n_all * sizeof(uint32_t), stream));

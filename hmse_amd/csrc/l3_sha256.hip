@@ -146,6 +146,7 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   if (!data || !cuts || !digests) return HMSE_EINVAL;
   if (!ws || ws_bytes < 8) return HMSE_ENOSPC;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
   // persistent grid: enough lanes to cover the chunks, at most 8 workgroups of 256 per CU (256 CUs)
   uint64_t blocks = (n_chunks + 255) / 256;

@@ -107,6 +107,7 @@ extern "C" int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* 
   const size_t need = (size_t)slots * 4 * cfg->bands;
   if (!ws || ws_bytes < need) return HMSE_ENOSPC;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   HMSE_HIP(hipMemsetAsync(ws, 0xFF, need, stream));
   const uint64_t nb = n_sel * cfg->bands;
   lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, n_sel, cfg->bands, cfg->rows, band_keys);

@@ -131,6 +131,7 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
   if (!data || !cuts || !sig) return HMSE_EINVAL;
   if (n_sel > 0x7FFFFFFFull) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   PROF_BEGIN(HMSE_STAGE_L4_MINHASH, stream);
   l4_minhash_kernel<<<dim3((uint32_t)n_sel), dim3(MH_NT), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig);
   PROF_END(HMSE_STAGE_L4_MINHASH, stream);
