@@ -22,9 +22,6 @@ namespace dfl {
 constexpr int HB = 12;
 constexpr int NBK = 1 << HB;
 constexpr uint32_t MINM = 4, MAXM = 258, WMAX = 32768;
-constexpr int NT = 512;             // threads per workgroup
-constexpr int WCAP = 65536;         // max dictionary + chunk
-constexpr int LCAP = 32768;         // max chunk
 
 __device__ __forceinline__ uint32_t hash4(uint32_t x) { return (x * 0x9E3779B1u) >> (32 - HB); }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -56,40 +53,67 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-struct HuffScratch {
-  uint32_t key[288];     // compacted (freq << 9 | sym)
-  uint32_t sorted[288];  // ascending
-  uint32_t w[576];       // node weights: leaves then internals
-  uint16_t parent[576];
-  uint32_t cnt[32];      // codes per length
-  uint32_t m;            // used symbols
+template <int N>
+struct HuffScratchT {
+  uint32_t key[N];         // compacted (freq << 9 | sym)
+  uint32_t sorted[N];      // ascending
+  uint32_t w[2 * N];       // node weights: leaves then internals
+  uint16_t parent[2 * N];
+  uint32_t cnt[32];        // codes per length
 };
+using HuffL = HuffScratchT<288>;
+using HuffD = HuffScratchT<32>;
 
-struct Shared {
-  __attribute__((aligned(16))) uint8_t W[WCAP + 32];
-  __attribute__((aligned(16))) uint32_t out[(LCAP + 64) / 4];
-  uint32_t cur[NBK];
-  uint32_t mark[LCAP / 32 + 2];
+// small per-workgroup state (always in LDS)
+template <int NT>
+struct Small {
   uint32_t lf[288], df[32], cf[20];
   uint8_t ll[288], dl[32], cl[20];
   uint16_t lc[288], dc[32], cc[20];
-  HuffScratch hs[2];
   uint8_t rle_sym[352], rle_eb[352], rle_ev[352];
   uint32_t red[NT / 64 + 1];
-  uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, total_bits;
-  unsigned long long job;
+  uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
+  uint32_t job, qhead;
+  uint32_t pexit[NT / 64];
+};
+
+constexpr int align16(int v) { return (v + 15) & ~15; }
+
+// LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
+// !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
+template <int NT, int TCAP, bool LDSM>
+struct Layout {
+  static constexpr int LCAP = LDSM ? TCAP : 32768;
+  static constexpr int W_OFF = 0;
+  static constexpr int W_SZ = align16(TCAP + 32);
+  static constexpr int CUR_OFF = W_OFF + W_SZ;          // u32[NBK] bucket cursors; later the Huffman scratch
+  static constexpr int CUR_SZ = NBK * 4;
+  static constexpr int MARK_OFF = CUR_OFF + CUR_SZ;
+  static constexpr int MARK_SZ = align16(LCAP / 8 + 16);
+  static constexpr int SMALL_OFF = MARK_OFF + MARK_SZ;
+  static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT>));
+  static constexpr int A_OFF = SMALL_OFF + SMALL_SZ;    // LDSM: u16 S[T] -> u16 jump[L+1] -> out image; !LDSM: out image
+  static constexpr int A_SZ = LDSM ? align16(2 * TCAP + 80) : align16(LCAP + 80);
+  static constexpr int MD_OFF = A_OFF + A_SZ;           // LDSM: u16 mdist[L]
+  static constexpr int MD_SZ = LDSM ? align16(2 * LCAP) : 0;
+  static constexpr int ML_OFF = MD_OFF + MD_SZ;         // LDSM: u8 mlen[L]
+  static constexpr int ML_SZ = LDSM ? align16(LCAP) : 0;
+  static constexpr int TOTAL = ML_OFF + ML_SZ;
+  static_assert(!LDSM || MD_SZ + ML_SZ >= 2 * TCAP, "the rank-sort temporary must fit the match arrays");
+  static_assert(sizeof(HuffL) + sizeof(HuffD) <= CUR_SZ, "Huffman scratch must fit the cursor table");
 };
 
 // ---- wave-level Huffman length construction (one wavefront, mirrors oracle huff_lengths) --------
-__device__ void huff_lengths_wave(uint32_t* freq, uint32_t n, uint32_t limit, uint8_t* lens, HuffScratch* hs) {
+template <typename HS>
+__device__ void huff_lengths_wave(const uint32_t* freq, uint32_t n, uint32_t limit, uint8_t* lens, HS* hs) {
   const uint32_t lane = lane_id();
-  // (1) at least two used symbols: the lowest unused indices get frequency 1
+  // (1) at least two used symbols: the lowest unused indices count as frequency 1
+  // (the histogram itself is left untouched: dummies only exist inside the tree construction)
   uint32_t used = 0;
   for (uint32_t b = 0; b < n; b += 64) {
     const uint32_t s = b + lane;
     used += (uint32_t)__builtin_popcountll(__ballot(s < n && freq[s] != 0));
   }
-  // (the histogram itself is left untouched: dummies only exist inside the tree construction)
   uint32_t dummy0 = 0xFFFFFFFFu, dummy1 = 0xFFFFFFFFu;
   if (used == 0) { dummy0 = 0; dummy1 = 1; }
   else if (used == 1) dummy0 = freq[0] != 0 ? 1u : 0u;
@@ -133,7 +157,6 @@ __device__ void huff_lengths_wave(uint32_t* freq, uint32_t n, uint32_t limit, ui
       hs->parent[pick0] = (uint16_t)ni; hs->parent[pick1] = (uint16_t)ni;
       ni++;
     }
-    hs->m = m;
   }
   wave_sync();
   // (5) leaf depths by walking to the root; histogram of depths clamped to the limit
@@ -166,32 +189,32 @@ __device__ void huff_lengths_wave(uint32_t* freq, uint32_t n, uint32_t limit, ui
   wave_sync();
 }
 
-// canonical codes (bit-reversed for LSB-first packing); one wavefront
-__device__ void huff_codes_wave(const uint8_t* lens, uint32_t n, uint16_t* codes, uint32_t* cnt /*>=32 u32 scratch*/) {
+// canonical codes (bit-reversed for LSB-first packing); one wavefront.  cnt: >= 48 u32 of LDS scratch
+// (cnt[0..15] codes per length, cnt[16..31] first code of each length, advanced block by block).
+__device__ void huff_codes_wave(const uint8_t* lens, uint32_t n, uint16_t* codes, uint32_t* cnt) {
   const uint32_t lane = lane_id();
   if (lane < 32) cnt[lane] = 0;
   wave_sync();
   for (uint32_t s = lane; s < n; s += 64) if (lens[s]) atomicAdd(&cnt[lens[s]], 1u);
   wave_sync();
-  uint32_t next[16];
-  {
-    uint32_t code = 0, prev = 0;
-    next[0] = 0;
-    for (uint32_t b = 1; b <= 15; b++) { code = (code + prev) << 1; next[b] = code; prev = cnt[b]; }
+  if (lane >= 1 && lane <= 15) {  // next_code[b] = sum_{j<b} cnt[j] << (b-j)   (RFC 1951 3.2.2)
+    uint32_t code = 0;
+    for (uint32_t j = 1; j < lane; j++) code += cnt[j] << (lane - j);
+    cnt[16 + lane] = code;
   }
+  wave_sync();
   // a symbol's code = next[len] + (#earlier symbols with the same length)
-  uint32_t run[16];
-#pragma unroll
-  for (int b = 0; b < 16; b++) run[b] = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += 64) {
     const uint32_t s = b0 + lane;
     const uint32_t l = s < n ? lens[s] : 0u;
     uint32_t mycode = 0;
-#pragma unroll
     for (uint32_t b = 1; b <= 15; b++) {
       const uint64_t mask = __ballot(l == b);
-      if (l == b) mycode = next[b] + run[b] + (uint32_t)__builtin_popcountll(mask & lanemask_lt());
-      run[b] += (uint32_t)__builtin_popcountll(mask);
+      if (mask == 0) continue;
+      if (l == b) mycode = cnt[16 + b] + (uint32_t)__builtin_popcountll(mask & lanemask_lt());
+      wave_sync();
+      if (lane == 0) cnt[16 + b] += (uint32_t)__builtin_popcountll(mask);
+      wave_sync();
     }
     if (s < n) codes[s] = l ? (uint16_t)(__builtin_bitreverse32(mycode) >> (32 - l)) : (uint16_t)0;
   }
@@ -205,6 +228,80 @@ __device__ __forceinline__ void put_bits(uint32_t* out, uint32_t off, uint32_t v
   if (s + nb > 32) atomicOr(&out[w + 1], v >> (32 - s));
 }
 
+// Code-length RLE of one tree, closed form per run (identical tokens to the oracle's loop):
+//   zero run R:      R/138 x (18,138), then rem>=11 -> (18,rem) | rem>=3 -> (17,rem) | rem literal zeros
+//   non-zero run R:  the value, then (R-1)/6 x (16,6), then rem>=3 -> (16,rem) | rem literals
+// One wavefront; tokens are appended at sm->nr (lane 0 keeps the count).
+template <int NT>
+__device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint32_t tok_base, uint32_t* tok_end) {
+  const uint32_t lane = lane_id();
+  uint64_t starts[5];
+  uint32_t val[5];
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    const uint32_t i = b * 64 + lane;
+    const uint32_t v = i < n ? l[i] : 0xFFu;
+    const uint32_t pv = (i > 0 && i < n) ? l[i - 1] : 0x1FFu;
+    val[b] = v;
+    starts[b] = __ballot(i < n && (i == 0 || v != pv));
+  }
+  uint32_t base = tok_base;
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    const uint32_t i = b * 64 + lane;
+    const bool is_start = (starts[b] >> lane) & 1ull;
+    // next run start after i (or n)
+    uint32_t nxt = n;
+    {
+      bool found = false;
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        if (c < b) continue;
+        uint64_t m = starts[c];
+        if (c == b) m &= (lane == 63) ? 0ull : (~0ull << (lane + 1));
+        if (!found && m) { nxt = c * 64 + (uint32_t)__builtin_ctzll(m); found = true; }
+      }
+    }
+    const uint32_t v = val[b];
+    uint32_t R = is_start ? nxt - i : 0u;
+    uint32_t cnt = 0, full = 0, rem = 0;
+    if (is_start) {
+      if (v == 0) { full = R / 138; rem = R % 138; cnt = full + (rem >= 3 ? 1u : rem); }
+      else { const uint32_t r1 = R - 1; full = r1 / 6; rem = r1 % 6; cnt = 1 + full + (rem >= 3 ? 1u : rem); }
+    }
+    // exclusive scan of cnt over the wave
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
+    const uint32_t tot = __shfl(inc, 63, 64);
+    uint32_t at = base + inc - cnt;
+    if (is_start) {
+      if (v == 0) {
+        for (uint32_t k = 0; k < full; k++) { sm->rle_sym[at] = 18; sm->rle_eb[at] = 7; sm->rle_ev[at] = 127; at++; }
+        if (rem >= 11) { sm->rle_sym[at] = 18; sm->rle_eb[at] = 7; sm->rle_ev[at] = (uint8_t)(rem - 11); at++; }
+        else if (rem >= 3) { sm->rle_sym[at] = 17; sm->rle_eb[at] = 3; sm->rle_ev[at] = (uint8_t)(rem - 3); at++; }
+        else for (uint32_t k = 0; k < rem; k++) { sm->rle_sym[at] = 0; sm->rle_eb[at] = 0; sm->rle_ev[at] = 0; at++; }
+      } else {
+        sm->rle_sym[at] = (uint8_t)v; sm->rle_eb[at] = 0; sm->rle_ev[at] = 0; at++;
+        for (uint32_t k = 0; k < full; k++) { sm->rle_sym[at] = 16; sm->rle_eb[at] = 2; sm->rle_ev[at] = 3; at++; }
+        if (rem >= 3) { sm->rle_sym[at] = 16; sm->rle_eb[at] = 2; sm->rle_ev[at] = (uint8_t)(rem - 3); at++; }
+        else for (uint32_t k = 0; k < rem; k++) { sm->rle_sym[at] = (uint8_t)v; sm->rle_eb[at] = 0; sm->rle_ev[at] = 0; at++; }
+      }
+    }
+    base += tot;
+  }
+  *tok_end = base;
+  wave_sync();
+}
+
+#ifdef HMSE_DFL_STAMPS
+// diagnostic build only: per-phase shader-clock totals of thread 0, summed over jobs and workgroups
+__device__ unsigned long long g_dfl_stamps[3][16];
+#define STAMP(i) do { if (t == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 struct Args {
   const uint8_t* data; uint64_t n;
   const uint64_t* cuts; const uint64_t* chunk_ids; const int64_t* base; uint64_t n_sel;
@@ -213,40 +310,58 @@ struct Args {
   uint8_t* slots;            // FULL stream at slot_off[k], DELTA stream at slot_off[k] + slot_stride(len)
   uint64_t slot_cap; uint32_t* status;
   uint32_t* len_full; uint32_t* len_delta;
-  uint8_t* scratch; size_t scratch_stride;
-  unsigned long long* counter;
+  uint8_t* scratch; size_t scratch_stride;   // !LDSM only
+  const uint32_t* jobs; const uint32_t* n_jobs; uint32_t* counter;  // this class's job list
 };
 
 __device__ __forceinline__ uint32_t slot_stride(uint32_t len) { return (len + 5 + 15) & ~15u; }
 
-// per-workgroup global scratch layout
+// per-workgroup global scratch of the big class
 struct Scratch {
-  uint16_t S1[WCAP]; uint16_t S[WCAP];
-  uint16_t jumpA[LCAP + 8]; uint16_t jumpB[LCAP + 8];
-  uint16_t mdist[LCAP]; uint8_t mlen[LCAP];
+  uint16_t S1[65536]; uint16_t S[65536];
+  uint16_t jumpA[32768 + 8]; uint16_t jumpB[32768 + 8];
+  uint16_t mdist[32768]; uint8_t mlen[32768];
 };
 
-__global__ __launch_bounds__(NT) void l1_deflate_kernel(Args a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-  Shared& sh = *reinterpret_cast<Shared*>(smem_raw);
-  Scratch& sc = *reinterpret_cast<Scratch*>(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
+template <int NT, int TCAP, bool LDSM>
+__global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) {
+  using LY = Layout<NT, TCAP, LDSM>;
+  constexpr int LCAP = LY::LCAP;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const W = smem + LY::W_OFF;
+  uint32_t* const cur = (uint32_t*)(smem + LY::CUR_OFF);
+  HuffL* const hsL = (HuffL*)(smem + LY::CUR_OFF);
+  HuffD* const hsD = (HuffD*)(smem + LY::CUR_OFF + sizeof(HuffL));
+  uint32_t* const mark = (uint32_t*)(smem + LY::MARK_OFF);
+  Small<NT>& sm = *(Small<NT>*)(smem + LY::SMALL_OFF);
+  uint32_t* const out = (uint32_t*)(smem + LY::A_OFF);
+  Scratch* const sc = LDSM ? nullptr : (Scratch*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
+  uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
+  uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
+  uint16_t* const mdist = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
+  uint8_t* const mlen = LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+  const uint32_t n_jobs = *a.n_jobs;
+#ifdef HMSE_DFL_STAMPS
+  unsigned long long stamp_acc[16] = {0}, stamp_last = clock64();
+#endif
 
   for (;;) {
     __syncthreads();
-    if (t == 0) sh.job = atomicAdd(a.counter, 1ull);
+    if (t == 0) sm.job = atomicAdd(a.counter, 1u);
     __syncthreads();
-    const unsigned long long job = sh.job;
-    if (job >= 2 * a.n_sel) break;
+    const uint32_t ji = sm.job;
+    if (ji >= n_jobs) break;
+    STAMP(10);
+    const uint32_t job = a.jobs[ji];
     const uint64_t k = job >> 1;
-    const uint32_t variant = (uint32_t)(job & 1);
-    const int64_t bsel = a.base ? a.base[k] : -1;
-    if (variant == 1 && bsel < 0) continue;
+    const uint32_t variant = job & 1u;
     const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
     const uint64_t cstart = a.cuts[c];
     const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
     uint32_t Dl = 0; uint64_t dstart = 0;
     if (variant == 1) {
+      const int64_t bsel = a.base[k];
       const uint64_t bc = a.chunk_ids ? a.chunk_ids[bsel] : (uint64_t)bsel;
       dstart = a.cuts[bc];
       uint64_t dl64 = a.cuts[bc + 1] - dstart;
@@ -255,229 +370,334 @@ __global__ __launch_bounds__(NT) void l1_deflate_kernel(Args a) {
     }
     uint8_t* slot = a.slots + a.slot_off[k] + (variant ? slot_stride(L) : 0u);
     uint32_t* len_out = variant ? a.len_delta : a.len_full;
-    if (L > LCAP || a.slot_off[k] + (variant + 1ull) * slot_stride(L) > a.slot_cap) {  // not encodable / no room: flagged
-      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= LCAP) atomicOr(a.status, 2u); }
+    const uint32_t T = Dl + L;
+    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.slot_off[k] + (variant + 1ull) * slot_stride(L) > a.slot_cap) {
+      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }
       continue;
     }
-    const uint32_t T = Dl + L;
     const uint8_t* csrc = a.data + cstart;
     const uint8_t* dsrc = a.data + dstart;
 
     // ---- phase 0: window into LDS, clear tables -----------------------------------------------
     for (uint32_t i = t * 16; i < Dl; i += NT * 16) {
-      if (i + 16 <= Dl) { const uint4 v = load_u4_unaligned(dsrc + i); __builtin_memcpy(sh.W + i, &v, 16); }
-      else for (uint32_t b = i; b < Dl; b++) sh.W[b] = dsrc[b];
+      if (i + 16 <= Dl) { const uint4 v = load_u4_unaligned(dsrc + i); __builtin_memcpy(W + i, &v, 16); }
+      else for (uint32_t b = i; b < Dl; b++) W[b] = dsrc[b];
     }
     for (uint32_t i = t * 16; i < L; i += NT * 16) {
-      if (i + 16 <= L) { const uint4 v = load_u4_unaligned(csrc + i); __builtin_memcpy(sh.W + Dl + i, &v, 16); }
-      else for (uint32_t b = i; b < L; b++) sh.W[Dl + b] = csrc[b];
+      if (i + 16 <= L) { const uint4 v = load_u4_unaligned(csrc + i); __builtin_memcpy(W + Dl + i, &v, 16); }
+      else for (uint32_t b = i; b < L; b++) W[Dl + b] = csrc[b];
     }
-    if (t < 32) sh.W[T + t] = 0;
-    for (uint32_t i = t; i < NBK; i += NT) sh.cur[i] = 0;
-    for (uint32_t i = t; i < LCAP / 32 + 2; i += NT) sh.mark[i] = 0;
-    for (uint32_t i = t; i < 288; i += NT) sh.lf[i] = 0;
-    if (t < 32) sh.df[t] = 0;
-    if (t < 20) sh.cf[t] = 0;
-    for (uint32_t i = t; i < (L + 64) / 4; i += NT) sh.out[i] = 0;
-    for (uint32_t i = t; i < L; i += NT) sc.mlen[i] = 0;
+    if (t < 32) W[T + t] = 0;
+    for (uint32_t i = t; i < NBK; i += NT) cur[i] = 0;
+    for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;
+    for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
+    if (t < 32) sm.df[t] = 0;
+    if (t < 20) sm.cf[t] = 0;
+    if (t == 0) sm.qhead = 0;
+    if constexpr (!LDSM) for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
     __syncthreads();
 
+    STAMP(0);
     // ---- phase 1-2: bucket histogram + exclusive scan -> bucket starts --------------------------
     const uint32_t nh = T >= 4 ? T - 3 : 0;
-    for (uint32_t q = t; q < nh; q += NT) atomicAdd(&sh.cur[hash4(ld32(sh.W + q))], 1u);
+    for (uint32_t q = t; q < nh; q += NT) atomicAdd(&cur[hash4(ld32(W + q))], 1u);
     __syncthreads();
     {
       constexpr int PER = NBK / NT;
       uint32_t loc[PER], sum = 0;
 #pragma unroll
-      for (int i = 0; i < PER; i++) { loc[i] = sh.cur[t * PER + i]; sum += loc[i]; }
+      for (int i = 0; i < PER; i++) { loc[i] = cur[t * PER + i]; sum += loc[i]; }
       uint32_t total;
-      uint32_t ex = block_exclusive_scan<NT>(sum, sh.red, &total);
+      uint32_t ex = block_exclusive_scan<NT>(sum, sm.red, &total);
 #pragma unroll
-      for (int i = 0; i < PER; i++) { sh.cur[t * PER + i] = ex; ex += loc[i]; }
+      for (int i = 0; i < PER; i++) { cur[t * PER + i] = ex; ex += loc[i]; }
     }
     __syncthreads();
-    // ---- phase 3: scatter (order inside a bucket is arbitrary here) -----------------------------
-    for (uint32_t q = t; q < nh; q += NT) {
-      const uint32_t slot_i = atomicAdd(&sh.cur[hash4(ld32(sh.W + q))], 1u);
-      sc.S1[slot_i] = (uint16_t)q;
-    }
-    __syncthreads();  // cur[h] now = end of bucket h
-    // ---- phase 4: rank inside the bucket -> ascending positions ---------------------------------
-    for (uint32_t i = t; i < nh; i += NT) {
-      const uint32_t q = sc.S1[i];
-      const uint32_t h = hash4(ld32(sh.W + q));
-      const uint32_t lo = h ? sh.cur[h - 1] : 0u, hi = sh.cur[h];
-      uint32_t r = 0;
-      for (uint32_t j = lo; j < hi; j++) r += sc.S1[j] < q;
-      sc.S[lo + r] = (uint16_t)q;
-    }
-    __syncthreads();
-    // ---- phase 5: longest match for every chunk position ----------------------------------------
-    for (uint32_t i = t; i < nh; i += NT) {
-      const uint32_t p = sc.S[i];
-      if (p < Dl) continue;
-      const uint32_t h = hash4(ld32(sh.W + p));
-      const uint32_t lo = h ? sh.cur[h - 1] : 0u;
-      const uint32_t maxlen = (T - p) < MAXM ? (T - p) : MAXM;
-      uint32_t best = MINM - 1, bd = 0;
-      for (uint32_t kk = 1; kk <= a.depth && i >= lo + kk; kk++) {
-        const uint32_t q = sc.S[i - kk];
-        if (p - q > WMAX) break;
-        if (sh.W[q + best] != sh.W[p + best]) continue;  // cannot beat the current best
-        uint32_t ml = 0;
-        while (ml < maxlen) {
-          const uint32_t x = ld32(sh.W + q + ml) ^ ld32(sh.W + p + ml);
-          if (x) { ml += (uint32_t)__builtin_ctz(x) >> 3; break; }
-          ml += 4;
-        }
-        if (ml > maxlen) ml = maxlen;
-        if (ml > best) { best = ml; bd = p - q; if (ml == maxlen) break; }
+    STAMP(1);
+    // ---- phase 3-4: scatter, then rank inside the bucket -> ascending positions -------------------
+    {
+      // unsorted bucket contents go to a temporary: the match arrays (not yet in use) in LDS mode
+      uint16_t* const S1 = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->S1;
+      for (uint32_t q = t; q < nh; q += NT) S1[atomicAdd(&cur[hash4(ld32(W + q))], 1u)] = (uint16_t)q;
+      __syncthreads();  // cur[h] now = end of bucket h
+      for (uint32_t i = t; i < nh; i += NT) {
+        const uint32_t q = S1[i];
+        const uint32_t h = hash4(ld32(W + q));
+        const uint32_t lo = h ? cur[h - 1] : 0u, hi = cur[h];
+        uint32_t r = 0;
+        for (uint32_t jj = lo; jj < hi; jj++) r += S1[jj] < q;
+        S[lo + r] = (uint16_t)q;
       }
-      if (best >= MINM) { sc.mlen[p - Dl] = (uint8_t)(best - 3); sc.mdist[p - Dl] = (uint16_t)bd; }
+      __syncthreads();
+      if constexpr (LDSM) {  // the temporary overlapped mlen/mdist: clear mlen now
+        for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
+        __syncthreads();
+      }
+    }
+    STAMP(2);
+    // ---- phase 5: longest match for every chunk position ----------------------------------------
+    // Bucket sizes and match lengths are heavily skewed (a few hot 4-grams hold most candidates), so a
+    // lane does NOT own a fixed set of positions: every lane is a small state machine that pulls the
+    // next sorted rank from an LDS counter when it has finished one, and advances by one unit of work
+    // per iteration (fetch / probe one candidate / extend a long compare by 8 bytes).  Per candidate:
+    // one u16 read of the bucket array and one 4-byte probe at offset best-3 (a longer match must agree
+    // there); the first 16 bytes of the p side are compared from registers.  Candidate order per
+    // position is unchanged (nearest first), so results equal the oracle's serial walk.
+    {
+      enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
+      uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0;
+      uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+      for (;;) {
+        if (st == FETCH) {
+          uint32_t ii;
+          do { ii = atomicAdd(&sm.qhead, 1u); } while (ii < nh && S[ii] < Dl);
+          if (ii >= nh) st = DONE;
+          else {
+            i = ii; p = S[i];
+            qn = i ? S[i - 1] : 0u;  // first candidate (valid iff kmax != 0)
+            pw0 = ld32(W + p); pw1 = ld32(W + p + 4); pw2 = ld32(W + p + 8); pw3 = ld32(W + p + 12);
+            const uint32_t h = hash4(pw0);
+            const uint32_t lo = h ? cur[h - 1] : 0u;
+            maxlen = (T - p) < MAXM ? (T - p) : MAXM;
+            kmax = i - lo;
+            if (kmax > a.depth) kmax = a.depth;
+            best = MINM - 1; bd = 0; probe = pw0; kk = 1;
+            if (kmax != 0) st = PROBE;  // an empty bucket prefix: no match, fetch again next iteration
+          }
+        }
+        if (__ballot(st != DONE) == 0) break;
+        bool fin = false;  // candidate kk finished with length ml
+        if (st == PROBE) {
+          q = qn;
+          // all LDS reads of this step are independent: one latency, not a chain
+          const uint32_t cprobe = ld32(W + q + best - 3);
+          const uint32_t c0 = ld32(W + q), c1 = ld32(W + q + 4), c2 = ld32(W + q + 8), c3 = ld32(W + q + 12);
+          qn = (kk < kmax) ? S[i - kk - 1] : 0u;  // prefetch the next candidate
+          fin = true;
+          if (TCAP > (int)WMAX && p - q > WMAX) { kk = kmax; ml = 0; }  // farther ones are farther still
+          else if (cprobe != probe) ml = 0;                            // cannot beat the current best
+          else {
+            uint32_t x;
+            if ((x = c0 ^ pw0) != 0) ml = (uint32_t)__builtin_ctz(x) >> 3;
+            else if ((x = c1 ^ pw1) != 0) ml = 4 + ((uint32_t)__builtin_ctz(x) >> 3);
+            else if ((x = c2 ^ pw2) != 0) ml = 8 + ((uint32_t)__builtin_ctz(x) >> 3);
+            else if ((x = c3 ^ pw3) != 0) ml = 12 + ((uint32_t)__builtin_ctz(x) >> 3);
+            else { ml = 16; if (maxlen > 16) { fin = false; st = EXTEND; } }
+          }
+        } else if (st == EXTEND) {
+          uint64_t xa, xb, ya, yb;
+          __builtin_memcpy(&xa, W + q + ml, 8); __builtin_memcpy(&xb, W + p + ml, 8);
+          __builtin_memcpy(&ya, W + q + ml + 8, 8); __builtin_memcpy(&yb, W + p + ml + 8, 8);
+          const uint64_t x = xa ^ xb, y = ya ^ yb;
+          if (x) { ml += (uint32_t)__builtin_ctzll(x) >> 3; fin = true; }
+          else if (y) { ml += 8 + ((uint32_t)__builtin_ctzll(y) >> 3); fin = true; }
+          else { ml += 16; if (ml >= maxlen) fin = true; }
+        }
+        if (fin) {
+          if (ml > maxlen) ml = maxlen;
+          bool pos_done = false;
+          if (ml > best) {
+            best = ml; bd = p - q;
+            if (ml == maxlen) pos_done = true; else probe = ld32(W + p + best - 3);
+          }
+          if (++kk > kmax) pos_done = true;
+          st = PROBE;
+          if (pos_done) {
+            if (best >= MINM) { mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd; }
+            st = FETCH;
+          }
+        }
+      }
     }
     __syncthreads();
+    STAMP(3);
     // ---- phase 6: parse by pointer doubling -------------------------------------------------------
     auto take = [&](uint32_t x) -> bool {
-      const uint32_t ml = sc.mlen[x];
-      return ml != 0 && !(x + 1 < L && sc.mlen[x + 1] > ml);
+      const uint32_t ml = mlen[x];
+      return ml != 0 && !(x + 1 < L && mlen[x + 1] > ml);
     };
     for (uint32_t x = t; x <= L; x += NT) {
       uint32_t nx = L;
-      if (x < L) { nx = x + (take(x) ? (uint32_t)sc.mlen[x] + 3u : 1u); if (nx > L) nx = L; }
-      sc.jumpA[x] = (uint16_t)nx;
+      if (x < L) { nx = x + (take(x) ? (uint32_t)mlen[x] + 3u : 1u); if (nx > L) nx = L; }
+      jump[x] = (uint16_t)nx;
     }
-    if (t == 0 && L > 0) sh.mark[0] = 1u;
     __syncthreads();
+    // The parse chain 0 -> next(0) -> ... is serial, but LZ parses re-synchronise: chains started at
+    // different positions usually merge after a few tokens.  So every wavefront walks its own segment
+    // speculatively from the segment start (64 positions per step: the window's `next` values sit in one
+    // VGPR and the walk inside the window is a chain of v_readlane, no memory latency), then wave 0
+    // stitches the segments in order: from the true entry of a segment it walks only until it meets a
+    // speculatively marked position, keeps the speculative marks from there on and drops the ones before.
     {
-      uint16_t* ja = sc.jumpA; uint16_t* jb = sc.jumpB;
-      for (int round = 0; round < 17; round++) {
-        if (L == 0 || ja[0] == L) break;  // uniform: every chain position is already marked
-        for (uint32_t x = t; x < L; x += NT) {
-          if ((sh.mark[x >> 5] >> (x & 31)) & 1u) {
-            const uint32_t j = ja[x];
-            if (j < L) atomicOr(&sh.mark[j >> 5], 1u << (j & 31));
+      constexpr uint32_t NW = NT / 64;
+      const uint32_t SEG = (((L + NW - 1) / NW) + 63u) & ~63u;
+      {
+        const uint32_t sw = wave * SEG;
+        const uint32_t send = (sw + SEG) < L ? (sw + SEG) : L;
+        uint32_t curp = sw;
+        for (uint32_t wb = sw; wb < send; wb += 64) {
+          const uint32_t x = wb + lane;
+          const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
+          const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
+          uint64_t m = 0;
+          while (curp < wend) {
+            m |= 1ull << (curp - wb);
+            curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
           }
-          const uint32_t j1 = ja[x];
-          jb[x] = j1 < L ? ja[j1] : (uint16_t)L;
+          if (lane == 0) { mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32); }
         }
-        if (t == 0) jb[L] = (uint16_t)L;
-        __syncthreads();
-        uint16_t* tmp = ja; ja = jb; jb = tmp;
+        if (lane == 0) sm.pexit[wave] = curp;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        uint32_t tru = sm.pexit[0];  // true exit of the segments stitched so far
+        for (uint32_t w = 1; w < NW; w++) {
+          const uint32_t sw = w * SEG;
+          if (sw >= L) break;
+          const uint32_t send = (sw + SEG) < L ? (sw + SEG) : L;
+          const uint32_t e = tru;
+          if (e == sw) { tru = sm.pexit[w]; continue; }  // the speculation started at the true entry
+          // windows that lie wholly before the true entry hold no true position
+          for (uint32_t wb = sw; wb < send && (wb + 64 <= e || e >= send); wb += 64)
+            if (lane == 0) { mark[wb >> 5] = 0; mark[(wb >> 5) + 1] = 0; }
+          uint32_t curp = e;
+          bool conv = false;
+          // every window from the entry's on is rewritten (a long match may jump over whole windows,
+          // whose speculative marks must go too) until the two chains meet
+          for (uint32_t wb = e & ~63u; wb < send && !conv; wb += 64) {
+            const uint32_t x = wb + lane;
+            const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
+            const uint64_t spec = (uint64_t)mark[wb >> 5] | ((uint64_t)mark[(wb >> 5) + 1] << 32);
+            const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
+            uint64_t m = 0;
+            while (curp < wend) {
+              if ((spec >> (curp - wb)) & 1ull) { conv = true; break; }
+              m |= 1ull << (curp - wb);
+              curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
+            }
+            if (conv) m |= spec & ~((1ull << (curp - wb)) - 1ull);  // speculative marks from the meeting point on
+            if (lane == 0) { mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32); }
+          }
+          tru = conv ? sm.pexit[w] : curp;
+        }
       }
     }
     __syncthreads();
+    STAMP(4);
+    // the output image overlays the (now dead) S/jump array
+    for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;
     // ---- phase 7: symbol histograms -----------------------------------------------------------------
     for (uint32_t x = t; x < L; x += NT) {
-      if ((sh.mark[x >> 5] >> (x & 31)) & 1u) {
+      if ((mark[x >> 5] >> (x & 31)) & 1u) {
         if (take(x)) {
           uint32_t code, eb, ev;
-          len_sym((uint32_t)sc.mlen[x] + 3u, code, eb, ev); atomicAdd(&sh.lf[code], 1u);
-          dist_sym(sc.mdist[x], code, eb, ev); atomicAdd(&sh.df[code], 1u);
-        } else atomicAdd(&sh.lf[sh.W[Dl + x]], 1u);
+          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev); atomicAdd(&sm.lf[code], 1u);
+          dist_sym(mdist[x], code, eb, ev); atomicAdd(&sm.df[code], 1u);
+        } else atomicAdd(&sm.lf[W[Dl + x]], 1u);
       }
     }
-    if (t == 0) atomicAdd(&sh.lf[256], 1u);
+    if (t == 0) atomicAdd(&sm.lf[256], 1u);
     __syncthreads();
-    // ---- phase 8: trees (wave 0: lit/len, wave 1: dist) ------------------------------------------------
-    // fixed / stored costs first (histograms are modified by the >= 2 symbols rule)
+    STAMP(5);
+    // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
+    if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
+    if (wave == 1) huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
     if (wave == 2) {
       uint32_t fb = 0, xb = 0;
-      for (uint32_t s = lane; s < 286; s += 64) { fb += sh.lf[s] * fixed_len(s); if (s >= 257) xb += sh.lf[s] * len_extra_bits(s); }
-      if (lane < 30) { fb += sh.df[lane] * 5u; xb += sh.df[lane] * dist_extra_bits(lane); }
+      for (uint32_t s = lane; s < 286; s += 64) { fb += sm.lf[s] * fixed_len(s); if (s >= 257) xb += sm.lf[s] * len_extra_bits(s); }
+      if (lane < 30) { fb += sm.df[lane] * 5u; xb += sm.df[lane] * dist_extra_bits(lane); }
       for (int d = 32; d > 0; d >>= 1) { fb += __shfl_down(fb, d, 64); xb += __shfl_down(xb, d, 64); }
-      if (lane == 0) { sh.hdr_bits = fb + xb + 3; sh.total_bits = xb; }  // hdr_bits: fixed total, total_bits: extra bits (temporaries)
+      if (lane == 0) { sm.fixed_bits = fb + xb + 3; sm.extra_bits = xb; }
     }
     __syncthreads();
-    if (wave == 0) huff_lengths_wave(sh.lf, 286, 15, sh.ll, &sh.hs[0]);
-    if (wave == 1) huff_lengths_wave(sh.df, 30, 15, sh.dl, &sh.hs[1]);
-    __syncthreads();
-    // ---- phase 9: code-length RLE, CL tree, block type (wave 0) -------------------------------------------
+    STAMP(6);
+    // ---- phase 9: code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) ---------------------------
     if (wave == 0) {
-      if (lane == 0) {
-        uint32_t nlit = 286; while (nlit > 257 && sh.ll[nlit - 1] == 0) nlit--;
-        uint32_t ndist = 30; while (ndist > 1 && sh.dl[ndist - 1] == 0) ndist--;
-        sh.nlit = nlit; sh.ndist = ndist;
-        uint32_t kq = 0;
-        for (int tree = 0; tree < 2; tree++) {
-          const uint8_t* l = tree ? sh.dl : sh.ll;
-          const uint32_t nn = tree ? ndist : nlit;
-          uint32_t i = 0;
-          while (i < nn) {
-            uint32_t j = i + 1;
-            while (j < nn && l[j] == l[i]) j++;
-            uint32_t run = j - i; const uint32_t v = l[i];
-            if (v == 0) {
-              while (run >= 11) { const uint32_t cc = run > 138 ? 138 : run; sh.rle_sym[kq] = 18; sh.rle_eb[kq] = 7; sh.rle_ev[kq] = (uint8_t)(cc - 11); kq++; run -= cc; }
-              if (run >= 3) { sh.rle_sym[kq] = 17; sh.rle_eb[kq] = 3; sh.rle_ev[kq] = (uint8_t)(run - 3); kq++; run = 0; }
-              while (run) { sh.rle_sym[kq] = 0; sh.rle_eb[kq] = 0; sh.rle_ev[kq] = 0; kq++; run--; }
-            } else {
-              sh.rle_sym[kq] = (uint8_t)v; sh.rle_eb[kq] = 0; sh.rle_ev[kq] = 0; kq++; run--;
-              while (run >= 3) { const uint32_t cc = run > 6 ? 6 : run; sh.rle_sym[kq] = 16; sh.rle_eb[kq] = 2; sh.rle_ev[kq] = (uint8_t)(cc - 3); kq++; run -= cc; }
-              while (run) { sh.rle_sym[kq] = (uint8_t)v; sh.rle_eb[kq] = 0; sh.rle_ev[kq] = 0; kq++; run--; }
-            }
-            i = j;
-          }
-        }
-        sh.nr = kq;
-        for (uint32_t i = 0; i < kq; i++) sh.cf[sh.rle_sym[i]]++;
+      uint32_t nlit = 286, ndist = 30;
+      {  // trailing zero lengths: highest used symbol via ballots
+        uint32_t hi = 0;
+        for (uint32_t b = 0; b < 320; b += 64) { const uint32_t s = b + lane; const uint64_t m = __ballot(s < 286 && sm.ll[s] != 0); if (m) hi = b + 64 - (uint32_t)__builtin_clzll(m); }
+        nlit = hi < 257 ? 257 : hi;
+        const uint64_t md = __ballot(lane < 30 && sm.dl[lane] != 0);
+        ndist = md ? 64 - (uint32_t)__builtin_clzll(md) : 1u;
       }
+      uint32_t e1, e2;
+      rle_tree_wave<NT>(sm.ll, nlit, &sm, 0, &e1);
+      rle_tree_wave<NT>(sm.dl, ndist, &sm, e1, &e2);
+      for (uint32_t i = lane; i < e2; i += 64) atomicAdd(&sm.cf[sm.rle_sym[i]], 1u);
+      if (lane == 0) { sm.nlit = nlit; sm.ndist = ndist; sm.nr = e2; }
       wave_sync();
-      huff_lengths_wave(sh.cf, 19, 7, sh.cl, &sh.hs[0]);
-      if (lane == 0) {
-        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        uint32_t ncl = 19; while (ncl > 4 && sh.cl[order[ncl - 1]] == 0) ncl--;
-        sh.ncl = ncl;
-        const uint32_t fixed_bits = sh.hdr_bits, extra = sh.total_bits;
-        uint32_t dyn = 3 + 14 + 3 * ncl + extra;
-        for (uint32_t i = 0; i < sh.nr; i++) dyn += sh.cl[sh.rle_sym[i]] + sh.rle_eb[i];
-        uint32_t dhdr = dyn - extra;  // header bits so far (3 + 14 + 3*ncl + cl tokens)
-        for (uint32_t s = 0; s < 286; s++) dyn += sh.lf[s] * sh.ll[s];
-        for (uint32_t s = 0; s < 30; s++) dyn += sh.df[s] * sh.dl[s];
-        const uint32_t stored = 8u * (5u + L);
-        uint32_t mode;
-        if (stored <= fixed_bits && stored <= dyn) mode = 0;
-        else if (fixed_bits <= dyn) mode = 1;
-        else mode = 2;
-        sh.mode = mode;
-        sh.hdr_bits = mode == 2 ? dhdr : 3u;
-      }
+      huff_lengths_wave(sm.cf, 19, 7, sm.cl, hsD);
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      const uint64_t mo = __ballot(lane < 19 && sm.cl[order[lane < 19 ? lane : 0]] != 0);
+      uint32_t ncl = mo ? 64 - (uint32_t)__builtin_clzll(mo) : 0u;
+      if (ncl < 4) ncl = 4;
+      uint32_t cb = 0;
+      for (uint32_t i = lane; i < e2; i += 64) cb += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
+      for (int d = 32; d > 0; d >>= 1) cb += __shfl_down(cb, d, 64);
+      if (lane == 0) { sm.ncl = ncl; sm.cl_bits = cb; }
+    }
+    if (wave == 1) {
+      uint32_t db = 0;
+      for (uint32_t s = lane; s < 286; s += 64) db += sm.lf[s] * sm.ll[s];
+      if (lane < 30) db += sm.df[lane] * sm.dl[lane];
+      for (int d = 32; d > 0; d >>= 1) db += __shfl_down(db, d, 64);
+      if (lane == 0) sm.data_bits = db;
     }
     __syncthreads();
-    const uint32_t mode = sh.mode;
+    if (t == 0) {
+      const uint32_t dhdr = 3 + 14 + 3 * sm.ncl + sm.cl_bits;
+      const uint32_t dyn = dhdr + sm.extra_bits + sm.data_bits;
+      const uint32_t stored = 8u * (5u + L);
+      uint32_t mode;
+      if (stored <= sm.fixed_bits && stored <= dyn) mode = 0;
+      else if (sm.fixed_bits <= dyn) mode = 1;
+      else mode = 2;
+      sm.mode = mode;
+      sm.hdr_bits = mode == 2 ? dhdr : 3u;
+    }
+    __syncthreads();
+    const uint32_t mode = sm.mode;
     if (mode == 0) {
       if (t == 0) {
         slot[0] = 1; slot[1] = (uint8_t)L; slot[2] = (uint8_t)(L >> 8); slot[3] = (uint8_t)~L; slot[4] = (uint8_t)(~L >> 8);
         len_out[k] = 5 + L;
       }
-      for (uint32_t x = t; x < L; x += NT) slot[5 + x] = sh.W[Dl + x];
+      for (uint32_t x = t; x < L; x += NT) slot[5 + x] = W[Dl + x];
       continue;
     }
+    STAMP(7);
     // ---- phase 10: code tables ------------------------------------------------------------------------------
     if (mode == 1) {
-      for (uint32_t s = t; s < 288; s += NT) sh.ll[s] = (uint8_t)fixed_len(s);
-      if (t < 32) sh.dl[t] = 5;
+      for (uint32_t s = t; s < 288; s += NT) sm.ll[s] = (uint8_t)fixed_len(s);
+      if (t < 32) sm.dl[t] = 5;
       __syncthreads();
     }
-    if (wave == 0) huff_codes_wave(sh.ll, mode == 1 ? 288 : 286, sh.lc, sh.hs[0].cnt);
-    if (wave == 1) huff_codes_wave(sh.dl, mode == 1 ? 32 : 30, sh.dc, sh.hs[1].cnt);
-    if (wave == 2 && mode == 2) huff_codes_wave(sh.cl, 19, sh.cc, sh.hs[1].key);
+    if (wave == 0) huff_codes_wave(sm.ll, mode == 1 ? 288 : 286, sm.lc, hsL->cnt);
+    if (wave == 1) huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
+    if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
     __syncthreads();
+    STAMP(8);
     // ---- phase 11: emit ----------------------------------------------------------------------------------------
-    if (t == 0) {
-      uint32_t off = 0;
-      put_bits(sh.out, off, 1, 1); off += 1;
-      put_bits(sh.out, off, mode, 2); off += 2;
+    if (wave == 0) {
+      if (lane == 0) { put_bits(out, 0, 1, 1); put_bits(out, 1, mode, 2); }
       if (mode == 2) {
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        put_bits(sh.out, off, sh.nlit - 257, 5); off += 5;
-        put_bits(sh.out, off, sh.ndist - 1, 5); off += 5;
-        put_bits(sh.out, off, sh.ncl - 4, 4); off += 4;
-        for (uint32_t i = 0; i < sh.ncl; i++) { put_bits(sh.out, off, sh.cl[order[i]], 3); off += 3; }
-        for (uint32_t i = 0; i < sh.nr; i++) {
-          const uint32_t s = sh.rle_sym[i];
-          put_bits(sh.out, off, sh.cc[s], sh.cl[s]); off += sh.cl[s];
-          if (sh.rle_eb[i]) { put_bits(sh.out, off, sh.rle_ev[i], sh.rle_eb[i]); off += sh.rle_eb[i]; }
+        if (lane == 0) { put_bits(out, 3, sm.nlit - 257, 5); put_bits(out, 8, sm.ndist - 1, 5); put_bits(out, 13, sm.ncl - 4, 4); }
+        if (lane < sm.ncl) put_bits(out, 17 + 3 * lane, sm.cl[order[lane]], 3);
+        // code-length tokens: contiguous token blocks per lane, wave prefix scan of their bit counts
+        const uint32_t nr = sm.nr, per = (nr + 63) / 64;
+        const uint32_t i0 = lane * per, i1 = (i0 + per) < nr ? (i0 + per) : nr;
+        uint32_t bits = 0;
+        for (uint32_t i = i0; i < i1; i++) bits += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
+        uint32_t inc = bits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
+        uint32_t off = 17 + 3 * sm.ncl + inc - bits;
+        for (uint32_t i = i0; i < i1; i++) {
+          const uint32_t s = sm.rle_sym[i], l = sm.cl[s], eb = sm.rle_eb[i];
+          put_bits(out, off, (uint32_t)sm.cc[s] | ((uint32_t)sm.rle_ev[i] << l), l + eb);
+          off += l + eb;
         }
       }
     }
@@ -486,41 +706,73 @@ __global__ __launch_bounds__(NT) void l1_deflate_kernel(Args a) {
     const uint32_t x0 = t * per, x1 = (x0 + per) < L ? (x0 + per) : L;
     uint32_t mybits = 0;
     for (uint32_t x = x0; x < x1; x++) {
-      if ((sh.mark[x >> 5] >> (x & 31)) & 1u) {
+      if ((mark[x >> 5] >> (x & 31)) & 1u) {
         if (take(x)) {
           uint32_t code, eb, ev, dcode, deb, dev;
-          len_sym((uint32_t)sc.mlen[x] + 3u, code, eb, ev);
-          dist_sym(sc.mdist[x], dcode, deb, dev);
-          mybits += sh.ll[code] + eb + sh.dl[dcode] + deb;
-        } else mybits += sh.ll[sh.W[Dl + x]];
+          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev);
+          dist_sym(mdist[x], dcode, deb, dev);
+          mybits += sm.ll[code] + eb + sm.dl[dcode] + deb;
+        } else mybits += sm.ll[W[Dl + x]];
       }
     }
     uint32_t total;
-    uint32_t off = block_exclusive_scan<NT>(mybits, sh.red, &total) + sh.hdr_bits;
+    uint32_t off = block_exclusive_scan<NT>(mybits, sm.red, &total) + sm.hdr_bits;
     for (uint32_t x = x0; x < x1; x++) {
-      if ((sh.mark[x >> 5] >> (x & 31)) & 1u) {
+      if ((mark[x >> 5] >> (x & 31)) & 1u) {
         if (take(x)) {
           uint32_t code, eb, ev, dcode, deb, dev;
-          len_sym((uint32_t)sc.mlen[x] + 3u, code, eb, ev);
-          dist_sym(sc.mdist[x], dcode, deb, dev);
-          const uint32_t l1 = sh.ll[code], l2 = sh.dl[dcode];
-          put_bits(sh.out, off, (uint32_t)sh.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
-          put_bits(sh.out, off, (uint32_t)sh.dc[dcode] | (dev << l2), l2 + deb); off += l2 + deb;
+          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev);
+          dist_sym(mdist[x], dcode, deb, dev);
+          const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
+          put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
+          put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb); off += l2 + deb;
         } else {
-          const uint32_t b = sh.W[Dl + x];
-          put_bits(sh.out, off, sh.lc[b], sh.ll[b]); off += sh.ll[b];
+          const uint32_t b = W[Dl + x];
+          put_bits(out, off, sm.lc[b], sm.ll[b]); off += sm.ll[b];
         }
       }
     }
-    const uint32_t end_bits = sh.hdr_bits + total;
-    if (t == 0) put_bits(sh.out, end_bits, sh.lc[256], sh.ll[256]);
+    const uint32_t end_bits = sm.hdr_bits + total;
+    if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
     __syncthreads();
-    const uint32_t nbytes = (end_bits + sh.ll[256] + 7) >> 3;
+    const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
     for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // slot is 16-byte aligned and padded
-      const uint4 v = *(const uint4*)((const uint8_t*)sh.out + i);
+      const uint4 v = *(const uint4*)((const uint8_t*)out + i);
       *(uint4*)(slot + i) = v;
     }
     if (t == 0) len_out[k] = nbytes;
+    STAMP(9);
+  }
+#ifdef HMSE_DFL_STAMPS
+  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[LDSM ? (TCAP <= 9216 ? 0 : 1) : 2][i], stamp_acc[i]);
+#endif
+}
+
+// size classes: everything in LDS for T <= 9216 (two workgroups per CU) and T <= 20480 (one per CU);
+// larger windows (up to 32 KiB chunk + 32 KiB dictionary) keep their per-position arrays in global scratch
+constexpr int NT_S = 512, TCAP_S = 9216;
+constexpr int NT_M = 1024, TCAP_M = 20480;
+constexpr int NT_B = 512, TCAP_B = 65536;
+
+// job = (k << 1) | variant, appended to its size class's list
+__global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
+                                                        const int64_t* __restrict__ base, uint64_t n_sel,
+                                                        uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_sel) return;
+  const uint64_t c = chunk_ids ? chunk_ids[k] : k;
+  const uint64_t L = cuts[c + 1] - cuts[c];
+  auto cls = [](uint64_t T) -> uint32_t { return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_M ? 1u : 2u; };
+  {
+    const uint32_t cl = cls(L);
+    lists[cl * list_stride + atomicAdd(&counts[cl], 1u)] = (uint32_t)(k << 1);
+  }
+  if (base && base[k] >= 0) {
+    const uint64_t bc = chunk_ids ? chunk_ids[base[k]] : (uint64_t)base[k];
+    uint64_t Dl = cuts[bc + 1] - cuts[bc];
+    if (Dl > WMAX) Dl = WMAX;
+    const uint32_t cl = cls(L + Dl);
+    lists[cl * list_stride + atomicAdd(&counts[cl], 1u)] = (uint32_t)((k << 1) | 1u);
   }
 }
 
@@ -635,29 +887,54 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
-constexpr int N_WG = 256;  // persistent workgroups (one per CU: the LDS image is > 80 KiB)
+constexpr int N_WG_B = 128;  // persistent workgroups of the big class (global scratch each)
 
 struct Ws {
-  unsigned long long* counter; uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
-  uint32_t* len_full; uint32_t* len_delta; uint8_t* scratch; uint8_t* slots; size_t fixed_bytes;
+  uint32_t* counters;  // [0..2] job counts per class, [4..6] job cursors
+  uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
+  uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
+  uint8_t* scratch; uint8_t* slots; size_t fixed_bytes;
 };
 static Ws carve(void* ws, uint64_t n_sel) {
   WsCarver w(ws, ~(size_t)0);
   Ws r;
-  r.counter = w.take<unsigned long long>(1);
+  r.counters = w.take<uint32_t>(16);
   r.slot_total = w.take<uint64_t>(1);
   r.slot_off = w.take<uint64_t>(n_sel + 1);
   r.final_len = w.take<uint64_t>(n_sel + 1);
   r.bsum = w.take<uint64_t>((n_sel + SC_NT - 1) / SC_NT + 1);
   r.len_full = w.take<uint32_t>(n_sel);
   r.len_delta = w.take<uint32_t>(n_sel);
-  r.scratch = w.take<uint8_t>((size_t)N_WG * hmse_align_up(sizeof(Scratch), 256));
+  r.list_stride = 2 * n_sel;
+  r.lists = w.take<uint32_t>(3 * r.list_stride);
+  r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
   r.fixed_bytes = w.off;
   r.slots = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
 }
 
+template <int NT, int TCAP, bool LDSM>
+static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
+  using LY = Layout<NT, TCAP, LDSM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LDSM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+      return HMSE_EHIP;
+    attr_set = true;
+  }
+  l1_deflate_kernel<NT, TCAP, LDSM><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
+}
+
 }  // namespace dfl
+
+#ifdef HMSE_DFL_STAMPS
+extern "C" int hmse_debug_deflate_stamps(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(dfl::g_dfl_stamps), sizeof(dfl::g_dfl_stamps)) != hipSuccess) return HMSE_EHIP;
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
+  return HMSE_OK;
+}
+#endif
 
 // fixed part only; the caller adds the slot area: sum over chunks of align16(len+5) * (1 + has_base)
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_sel, const hmse_cfg*) { return dfl::carve(nullptr, n_sel).fixed_bytes; }
@@ -679,27 +956,29 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   // slot area = whatever follows the fixed part; a job whose slot does not fit sets status bit 1
   // (needed: sum over selected chunks of align16(len+5), twice where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
-  HMSE_HIP(hipMemsetAsync(w.counter, 0, sizeof(unsigned long long), stream));
+  HMSE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(uint32_t), stream));
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
   slot_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.slot_off);
   HMSE_LAUNCH_CHECK();
   if (exclusive_scan_u64(w.slot_off, n_sel, w.slot_off, w.bsum, w.slot_total, stream) != HMSE_OK) return HMSE_EHIP;
+  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.lists, w.list_stride, w.counters);
+  HMSE_LAUNCH_CHECK();
   Args a;
   a.data = data; a.n = n; a.cuts = cuts; a.chunk_ids = chunk_ids; a.base = base; a.n_sel = n_sel;
   a.depth = hmse_deflate_depth(cfg);
   a.slot_off = w.slot_off; a.slots = w.slots; a.len_full = w.len_full; a.len_delta = w.len_delta;
   a.slot_cap = avail; a.status = status;
-  a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256); a.counter = w.counter;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HMSE_HIP(hipFuncSetAttribute((const void*)l1_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)));
-    attr_set = true;
-  }
-  uint64_t grid = 2 * n_sel < (uint64_t)N_WG ? 2 * n_sel : (uint64_t)N_WG;
+  a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
+  // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
+  const uint64_t max_jobs = 2 * n_sel;
   PROF_BEGIN(HMSE_STAGE_L1_DEFLATE, stream);
-  l1_deflate_kernel<<<dim3((uint32_t)grid), dim3(NT), sizeof(Shared), stream>>>(a);
+  a.jobs = w.lists; a.n_jobs = w.counters + 0; a.counter = w.counters + 4;
+  if (launch_class<NT_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
+  a.jobs = w.lists + w.list_stride; a.n_jobs = w.counters + 1; a.counter = w.counters + 5;
+  if (launch_class<NT_M, TCAP_M, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  a.jobs = w.lists + 2 * w.list_stride; a.n_jobs = w.counters + 2; a.counter = w.counters + 6;
+  if (launch_class<NT_B, TCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(HMSE_STAGE_L1_DEFLATE, stream);
-  HMSE_LAUNCH_CHECK();
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status);
   HMSE_LAUNCH_CHECK();

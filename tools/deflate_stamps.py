@@ -1,0 +1,39 @@
+"""Diagnostic: per-phase clock shares of the DEFLATE kernel (uses the -DHMSE_DFL_STAMPS build)."""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+from hmse_amd import IngestConfig, _lib, corpus, ops
+
+_lib.HIP_LIB_PATH = _lib.HIP_LIB_PATH.replace("libhmse_hip.so", "libhmse_hip_stamps.so")
+lib = _lib.hip_lib()
+lib.hmse_debug_deflate_stamps.argtypes = [C.c_void_p, C.c_int]
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+cfg = IngestConfig()
+dev = torch.device("cuda:0")
+d = torch.from_numpy(corpus.wiki_synth(mib << 20)).to(dev)
+cuts = ops.l2_cdc(d, cfg)
+dg = ops.l3_sha256(d, cuts)
+fo, _ = ops.l3_dedup(dg)
+uniq = (fo == torch.arange(fo.numel(), device=dev)).nonzero().flatten()
+sig = ops.l4_minhash(d, cuts, cfg, uniq)
+_, base = ops.l4_lsh(sig, cfg)
+ops.l1_deflate(d, cuts, cfg, uniq, base)
+torch.cuda.synchronize()
+buf = np.zeros(48, dtype=np.uint64)
+lib.hmse_debug_deflate_stamps(buf.ctypes.data, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
+lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
+names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch"]
+print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
+for c, cn in enumerate(["small", "medium", "big"]):
+    row = buf[c * 16:(c + 1) * 16].astype(np.float64)
+    tot = row.sum()
+    if tot == 0:
+        continue
+    print(cn, "total Mclk %.1f" % (tot / 1e6))
+    for i, nm in enumerate(names):
+        print("   %-18s %6.2f %%" % (nm, 100 * row[i] / tot))
