@@ -98,7 +98,9 @@ struct Layout {
   static constexpr int MD_SZ = LDSM ? align16(2 * LCAP) : 0;
   static constexpr int ML_OFF = MD_OFF + MD_SZ;         // LDSM: u8 mlen[L]
   static constexpr int ML_SZ = LDSM ? align16(LCAP) : 0;
-  static constexpr int TOTAL = ML_OFF + ML_SZ;
+  static constexpr int K_OFF = ML_OFF + ML_SZ;          // LDSM: u8 K[T] = byte 4 of the position at each sorted rank
+  static constexpr int K_SZ = LDSM ? align16(TCAP + 16) : 0;
+  static constexpr int TOTAL = K_OFF + K_SZ;
   static_assert(!LDSM || MD_SZ + ML_SZ >= 2 * TCAP, "the rank-sort temporary must fit the match arrays");
   static_assert(sizeof(HuffL) + sizeof(HuffD) <= CUR_SZ, "Huffman scratch must fit the cursor table");
 };
@@ -318,7 +320,7 @@ __device__ __forceinline__ uint32_t slot_stride(uint32_t len) { return (len + 5 
 
 // per-workgroup global scratch of the big class
 struct Scratch {
-  uint16_t S1[65536]; uint16_t S[65536];
+  uint16_t S1[65536]; uint16_t S[65536]; uint8_t K[65536 + 16];
   uint16_t jumpA[32768 + 8]; uint16_t jumpB[32768 + 8];
   uint16_t mdist[32768]; uint8_t mlen[32768];
 };
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
   uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
   uint16_t* const mdist = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
   uint8_t* const mlen = LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
+  uint8_t* const K = LDSM ? (uint8_t*)(smem + LY::K_OFF) : sc->K;
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
@@ -416,20 +419,30 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
     STAMP(1);
     // ---- phase 3-4: scatter, then rank inside the bucket -> ascending positions -------------------
     {
-      // unsorted bucket contents go to a temporary: the match arrays (not yet in use) in LDS mode
-      uint16_t* const S1 = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->S1;
-      for (uint32_t q = t; q < nh; q += NT) S1[atomicAdd(&cur[hash4(ld32(W + q))], 1u)] = (uint16_t)q;
-      __syncthreads();  // cur[h] now = end of bucket h
-      for (uint32_t i = t; i < nh; i += NT) {
-        const uint32_t q = S1[i];
-        const uint32_t h = hash4(ld32(W + q));
-        const uint32_t lo = h ? cur[h - 1] : 0u, hi = cur[h];
-        uint32_t r = 0;
-        for (uint32_t jj = lo; jj < hi; jj++) r += S1[jj] < q;
-        S[lo + r] = (uint16_t)q;
+      // Counting sort with ORDERED buckets.  Positions are scattered NT at a time in ascending order
+      // (two barriers per step), so bucket contents are already ordered between steps; inside one step
+      // the same-hash positions land in the contiguous slot range [before, after) of their bucket in
+      // arbitrary order and are ranked there (ranges hold a handful of entries: the quadratic rank is
+      // over the step's duplicates only, not over the whole bucket).
+      uint16_t* const S1 = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->S1;  // staging (match arrays, not yet in use)
+      for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
+        const uint32_t q = q0 + t;
+        const bool act = q < nh;
+        uint32_t h = 0, before = 0;
+        if (act) { h = hash4(ld32(W + q)); before = cur[h]; }
+        __syncthreads();
+        if (act) S1[atomicAdd(&cur[h], 1u)] = (uint16_t)q;
+        __syncthreads();
+        if (act) {
+          const uint32_t after = cur[h];
+          uint32_t r = 0;
+          for (uint32_t jj = before; jj < after; jj++) r += S1[jj] < q;
+          S[before + r] = (uint16_t)q;
+          K[before + r] = W[q + 4];
+        }
       }
-      __syncthreads();
-      if constexpr (LDSM) {  // the temporary overlapped mlen/mdist: clear mlen now
+      __syncthreads();  // cur[h] now = end of bucket h
+      if constexpr (LDSM) {  // the staging area overlapped mlen/mdist: clear mlen now
         for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
         __syncthreads();
       }
@@ -445,44 +458,53 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
     // position is unchanged (nearest first), so results equal the oracle's serial walk.
     {
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
-      uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0;
-      uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;
+      uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
+      uint32_t pw0 = 0, pw1 = 0;
       for (;;) {
-        if (st == FETCH) {
-          uint32_t ii;
-          do { ii = atomicAdd(&sm.qhead, 1u); } while (ii < nh && S[ii] < Dl);
-          if (ii >= nh) st = DONE;
-          else {
-            i = ii; p = S[i];
-            qn = i ? S[i - 1] : 0u;  // first candidate (valid iff kmax != 0)
-            pw0 = ld32(W + p); pw1 = ld32(W + p + 4); pw2 = ld32(W + p + 8); pw3 = ld32(W + p + 12);
-            const uint32_t h = hash4(pw0);
-            const uint32_t lo = h ? cur[h - 1] : 0u;
-            maxlen = (T - p) < MAXM ? (T - p) : MAXM;
-            kmax = i - lo;
-            if (kmax > a.depth) kmax = a.depth;
-            best = MINM - 1; bd = 0; probe = pw0; kk = 1;
-            if (kmax != 0) st = PROBE;  // an empty bucket prefix: no match, fetch again next iteration
+        const uint64_t need = __ballot(st == FETCH);
+        if (need) {  // wave-aggregated pull of the next sorted ranks
+          const uint32_t leader = (uint32_t)__builtin_ctzll(need);
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(&sm.qhead, (uint32_t)__builtin_popcountll(need));
+          base = (uint32_t)__shfl((int)base, (int)leader, 64);
+          if (st == FETCH) {
+            const uint32_t ii = base + (uint32_t)__builtin_popcountll(need & lanemask_lt());
+            if (ii >= nh) st = DONE;
+            else {
+              const uint32_t pp = S[ii];
+              if (pp >= Dl) {  // dictionary positions are candidates only: the lane pulls again next round
+                i = ii; p = pp;
+                qn = i ? S[i - 1] : 0u; kn = i ? K[i - 1] : 0u;  // first candidate (used iff kmax != 0)
+                pw0 = ld32(W + p); pw1 = ld32(W + p + 4);
+                const uint32_t h = hash4(pw0);
+                const uint32_t lo = h ? cur[h - 1] : 0u;
+                maxlen = (T - p) < MAXM ? (T - p) : MAXM;
+                kmax = i - lo;
+                if (kmax > a.depth) kmax = a.depth;
+                best = MINM - 1; bd = 0; probe = pw0; kk = 1;
+                if (kmax != 0) st = PROBE;  // first of its bucket: no match, pull again
+              }
+            }
           }
         }
         if (__ballot(st != DONE) == 0) break;
         bool fin = false;  // candidate kk finished with length ml
         if (st == PROBE) {
           q = qn;
-          // all LDS reads of this step are independent: one latency, not a chain
-          const uint32_t cprobe = ld32(W + q + best - 3);
-          const uint32_t c0 = ld32(W + q), c1 = ld32(W + q + 4), c2 = ld32(W + q + 8), c3 = ld32(W + q + 12);
-          qn = (kk < kmax) ? S[i - kk - 1] : 0u;  // prefetch the next candidate
-          fin = true;
-          if (TCAP > (int)WMAX && p - q > WMAX) { kk = kmax; ml = 0; }  // farther ones are farther still
-          else if (cprobe != probe) ml = 0;                            // cannot beat the current best
+          const uint32_t kb = kn;
+          if (kk < kmax) { qn = S[i - kk - 1]; kn = K[i - kk - 1]; }  // prefetch the next candidate (sequential, conflict-free)
+          fin = true; ml = 0;
+          if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
+          else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
           else {
+            // random-address window reads only for candidates that can still win
+            const uint32_t cprobe = ld32(W + q + best - 3);
+            const uint32_t c0 = ld32(W + q), c1 = ld32(W + q + 4);
             uint32_t x;
-            if ((x = c0 ^ pw0) != 0) ml = (uint32_t)__builtin_ctz(x) >> 3;
+            if (cprobe != probe) { }                                   // cannot beat the current best
+            else if ((x = c0 ^ pw0) != 0) ml = (uint32_t)__builtin_ctz(x) >> 3;
             else if ((x = c1 ^ pw1) != 0) ml = 4 + ((uint32_t)__builtin_ctz(x) >> 3);
-            else if ((x = c2 ^ pw2) != 0) ml = 8 + ((uint32_t)__builtin_ctz(x) >> 3);
-            else if ((x = c3 ^ pw3) != 0) ml = 12 + ((uint32_t)__builtin_ctz(x) >> 3);
-            else { ml = 16; if (maxlen > 16) { fin = false; st = EXTEND; } }
+            else { ml = 8; if (maxlen > 8) { fin = false; st = EXTEND; } }
           }
         } else if (st == EXTEND) {
           uint64_t xa, xb, ya, yb;
@@ -748,10 +770,10 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
 #endif
 }
 
-// size classes: everything in LDS for T <= 9216 (two workgroups per CU) and T <= 20480 (one per CU);
+// size classes: everything in LDS for T <= 8192 (two workgroups per CU) and T <= 18432 (one per CU);
 // larger windows (up to 32 KiB chunk + 32 KiB dictionary) keep their per-position arrays in global scratch
-constexpr int NT_S = 512, TCAP_S = 9216;
-constexpr int NT_M = 1024, TCAP_M = 20480;
+constexpr int NT_S = 512, TCAP_S = 8192;
+constexpr int NT_M = 1024, TCAP_M = 18432;
 constexpr int NT_B = 512, TCAP_B = 65536;
 
 // job = (k << 1) | variant, appended to its size class's list
