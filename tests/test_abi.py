@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hmse.h declares; host-side entry points
+(config, sizing, Gear table, error strings) behave; the device ops refuse to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "hmse.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hmse_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hmse_amd import _lib
+    lib = _lib.hip_lib()
+    names = declared_functions()
+    assert {"hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l4_minhash", "hmse_l4_lsh", "hmse_l1_deflate",
+            "hmse_workspace_bytes", "hmse_cfg_default", "hmse_cfg_validate"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hmse.h but not exported"
+    assert set(_lib.EXPORTED_SYMBOLS) == set(names)
+    assert lib.hmse_abi_version() == 1
+
+
+def test_cfg_default_matches_oracle_and_dataclass(orc):
+    from hmse_amd import IngestConfig, _lib
+    lib = _lib.hip_lib()
+    c = _lib.HmseCfg()
+    lib.hmse_cfg_default(C.byref(c))
+    o = orc.default_cfg()
+    d = IngestConfig().to_c()
+    assert C.sizeof(c) == 64 == c.struct_size
+    for name, _ in _lib.HmseCfg._fields_:
+        assert getattr(c, name) == getattr(o, name) == getattr(d, name), name
+    assert lib.hmse_cfg_validate(C.byref(c)) == 0
+
+
+@pytest.mark.parametrize("kw", [dict(min_size=32), dict(avg_size=6000), dict(max_size=65536), dict(n_hashes=64), dict(shingle=5),
+                                dict(bands=5), dict(level=10), dict(seg_size=1024), dict(norm_level=9)])
+def test_cfg_validate_rejects(kw):
+    from hmse_amd import IngestConfig, _lib
+    c = IngestConfig(**kw).to_c()
+    assert _lib.hip_lib().hmse_cfg_validate(C.byref(c)) == -1  # HMSE_EINVAL, like miniz/mbedtls negative status codes
+
+
+def test_reference_preset_and_ablations():
+    from hmse_amd import ABLATIONS, IngestConfig, _lib
+    p = IngestConfig.reference_preset()                      # README.md:2444-2446
+    assert (p.min_size, p.avg_size, p.max_size) == (1024, 4096, 16384)
+    assert _lib.hip_lib().hmse_cfg_validate(C.byref(p.to_c())) == 0
+    assert set(ABLATIONS) == {"l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only"}  # VALIDATION_METHODS.md:458-464
+    assert ABLATIONS["full"] == 15
+
+
+def test_gear_table_and_sizing_host_side(orc):
+    from hmse_amd import IngestConfig, _lib, ops
+    t = np.zeros(256, np.uint64)
+    _lib.hip_lib().hmse_gear_table(t.ctypes.data)
+    assert np.array_equal(t, orc.gear_table())
+    cfg = IngestConfig()
+    for stage in (2, 3, 4, 5, 6, 7):
+        assert ops.workspace_bytes(stage, 1 << 20, cfg) > 0
+    assert ops.workspace_bytes(2, 1 << 30, cfg) > ops.workspace_bytes(2, 1 << 20, cfg)
+    assert ops.workspace_bytes(99, 1, cfg) == 0
+    assert _lib.hip_lib().hmse_strerror(-2) == b"buffer or workspace too small"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback anywhere in hmse_amd: host tensors are refused."""
+    import torch
+    from hmse_amd import IngestConfig, ops
+    x = torch.zeros(1000, dtype=torch.uint8)
+    with pytest.raises(ops.HmseError):
+        ops.l2_cdc(x, IngestConfig())
+    with pytest.raises(ops.HmseError):
+        ops.l3_sha256(x, torch.tensor([0, 1000]))
+    with pytest.raises(ops.HmseError):
+        ops.l4_minhash(x, torch.tensor([0, 1000]), IngestConfig())
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hmse_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                src = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, fn

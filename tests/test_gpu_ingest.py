@@ -1,0 +1,160 @@
+"""GPU: the whole hot path through the host driver, against the oracle pipeline and through size-independent
+properties at larger sizes (round trips, determinism, sortedness, shard-count invariance)."""
+import hashlib
+import zlib
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def oracle_pipeline(orc, data, cfg, n_shards=1):
+    """CPU restatement of ingest_shard for n_shards contiguous segment runs: global dedupe, local LSH/DEFLATE."""
+    oc = orc.default_cfg(**asdict(cfg))
+    seg = cfg.seg_size
+    nseg = max(n_shards, data.size // seg)
+    bounds = [(r * nseg // n_shards) * seg for r in range(n_shards)] + [data.size]
+    shards = [data[bounds[r]:bounds[r + 1]] for r in range(n_shards)]
+    cuts = [orc.cdc(s, oc) for s in shards]
+    dg = [orc.sha256_chunks(s, c) for s, c in zip(shards, cuts)]
+    fo, rc = orc.dedup(np.concatenate(dg))
+    res, base0 = [], 0
+    for r in range(n_shards):
+        n = len(cuts[r]) - 1
+        fol = fo[base0:base0 + n]
+        uniq = np.nonzero(fol == np.arange(base0, base0 + n))[0].astype(np.uint64)
+        sig = orc.minhash_chunks(shards[r], cuts[r], oc, uniq)
+        keys, base = orc.lsh(sig, oc)
+        out, off, kind = orc.deflate_chunks(shards[r], cuts[r], oc, uniq, base)
+        res.append(dict(cuts=cuts[r], dg=dg[r], fo=fol, uniq=uniq, sig=sig, base=base, out=out, off=off, kind=kind, chunk_base=base0))
+        base0 += n
+    return shards, res
+
+
+def test_full_pipeline_equals_oracle_and_reconstructs(orc, dev):
+    import sys, os, torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import IngestConfig, corpus, ingest, manifest
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = np.concatenate([variants_dataset(corpus.wiki_synth(3 << 20, seed=42)), corpus.wiki_synth(2 << 20, seed=42)])
+    res = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    _, (o,) = oracle_pipeline(orc, data, cfg)
+    assert np.array_equal(res.cuts.cpu().numpy().astype(np.uint64), o["cuts"])
+    assert np.array_equal(res.digests.cpu().numpy(), o["dg"])
+    assert np.array_equal(res.first_occ.cpu().numpy().astype(np.uint64), o["fo"])
+    assert np.array_equal(res.uniq_ids.cpu().numpy().astype(np.uint64), o["uniq"])
+    assert np.array_equal(res.sig.cpu().numpy().view(np.uint32), o["sig"])
+    assert np.array_equal(res.base.cpu().numpy(), o["base"])
+    assert np.array_equal(res.kind.cpu().numpy(), o["kind"])
+    assert np.array_equal(res.stream_off.cpu().numpy().astype(np.uint64), o["off"])
+    assert np.array_equal(res.streams.cpu().numpy(), o["out"])
+    assert res.stats["delta"] > 10 and res.stats["pointer"] > 10
+    m = manifest.build_manifest(res)
+    assert manifest.reconstruct(manifest.Manifest.from_bytes(m.to_bytes())) == data.tobytes()   # 100 % lossless (VALIDATION_METHODS.md:257)
+
+
+@pytest.mark.parametrize("preset", ["l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only"])
+def test_ablation_matrix_runs_and_is_lossless(preset, dev):
+    """VALIDATION_METHODS.md:458-464: every layer subset produces a decodable result."""
+    import torch
+    from hmse_amd import ABLATIONS, IngestConfig, corpus, ingest
+    cfg = IngestConfig(layers=ABLATIONS[preset], seg_size=1 << 20)
+    data = corpus.wiki_synth(2 << 20, seed=42)
+    res = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    cuts = res.cuts.cpu().numpy()
+    assert cuts[0] == 0 and cuts[-1] == data.size and (np.diff(cuts) > 0).all() and np.diff(cuts).max() <= cfg.max_size
+    if res.streams is not None:
+        off = res.stream_off.cpu().numpy(); out = res.streams.cpu().numpy(); kind = res.kind.cpu().numpy()
+        uniq = res.uniq_ids.cpu().numpy(); base = res.base.cpu().numpy() if res.base is not None else None
+        for k in range(0, len(uniq), 7):
+            zd = data[cuts[uniq[base[k]]]:cuts[uniq[base[k]] + 1]].tobytes() if kind[k] == 2 else None
+            d = zlib.decompressobj(-15, zdict=zd) if zd else zlib.decompressobj(-15)
+            assert d.decompress(out[off[k]:off[k + 1]].tobytes()) == data[cuts[uniq[k]]:cuts[uniq[k] + 1]].tobytes()
+    else:
+        assert preset == "l4_only" and res.sig is not None
+
+
+def test_two_shard_run_equals_oracle_with_two_shards(orc, dev):
+    """Shard-count invariance without a second GPU: run both shards here, feed the concatenated digests to the
+    dedupe op exactly as the all-gather would, compare with the oracle's 2-shard pipeline."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ops
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(6 << 20, seed=42)
+    data[(4 << 20) + 5000:(5 << 20)] = data[5000:(1 << 20)]                       # cross-shard duplicates
+    shards, want = oracle_pipeline(orc, data, cfg, n_shards=2)
+    d = [torch.from_numpy(s).to(dev) for s in shards]
+    cuts = [ops.l2_cdc(x, cfg) for x in d]
+    dg = [ops.l3_sha256(x, c) for x, c in zip(d, cuts)]
+    fo, rc = ops.l3_dedup(torch.cat(dg))
+    base0 = 0
+    n_cross = 0
+    for r in range(2):
+        n = cuts[r].numel() - 1
+        fol = fo[base0:base0 + n]
+        assert np.array_equal(cuts[r].cpu().numpy().astype(np.uint64), want[r]["cuts"])
+        assert np.array_equal(fol.cpu().numpy().astype(np.uint64), want[r]["fo"])
+        uniq = (fol == torch.arange(base0, base0 + n, device=dev)).nonzero().flatten()
+        assert np.array_equal(uniq.cpu().numpy().astype(np.uint64), want[r]["uniq"])
+        sig = ops.l4_minhash(d[r], cuts[r], cfg, uniq)
+        _, base = ops.l4_lsh(sig, cfg)
+        out, off, kind = ops.l1_deflate(d[r], cuts[r], cfg, uniq, base)
+        assert np.array_equal(base.cpu().numpy(), want[r]["base"]) and np.array_equal(out.cpu().numpy(), want[r]["out"])
+        n_cross += int((fol < base0).sum())
+        base0 += n
+    assert n_cross > 50
+    # and the 1-shard cuts are the concatenation of the 2-shard cuts
+    c1 = ops.l2_cdc(torch.from_numpy(data).to(dev), cfg).cpu().numpy()
+    assert np.array_equal(c1, np.concatenate([want[0]["cuts"], want[1]["cuts"][1:] + np.uint64(shards[0].size)]).astype(np.int64))
+
+
+def test_properties_at_scale_256MiB(dev):
+    """Size-independent properties where the oracle would take minutes: determinism, sortedness, bounds,
+    digest spot checks, dedupe idempotence, signature/LSH invariants, DEFLATE round trips."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest
+    cfg = IngestConfig()
+    host = corpus.wiki_synth(256 << 20, seed=42)
+    data = torch.from_numpy(host).to(dev)
+    a = ingest.ingest_shard(data, cfg)
+    b = ingest.ingest_shard(data, cfg)
+    for f in ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "streams", "stream_off", "kind"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f                       # reruns bitwise identical
+    cuts = a.cuts.cpu().numpy()
+    sz = np.diff(cuts)
+    assert cuts[0] == 0 and cuts[-1] == host.size and (sz > 0).all() and sz.max() <= cfg.max_size
+    assert set(range(cfg.seg_size, host.size, cfg.seg_size)) <= set(cuts.tolist())
+    short_ends = cuts[1:][sz < cfg.min_size]
+    assert all(int(e) % cfg.seg_size == 0 or int(e) == host.size for e in short_ends)
+    rng = np.random.default_rng(0)
+    dg = a.digests.cpu().numpy()
+    for i in rng.integers(0, len(sz), 300):
+        assert dg[i].tobytes() == hashlib.sha256(host[cuts[i]:cuts[i + 1]].tobytes()).digest()
+    fo = a.first_occ.cpu().numpy(); rc = a.refcount.cpu().numpy()
+    assert (fo <= np.arange(len(fo))).all() and (fo[fo] == fo).all()              # idempotent, points backwards
+    assert rc.sum() == len(fo) and (rc[fo != np.arange(len(fo))] == 0).all()
+    assert (dg[fo] == dg).all()
+    base = a.base.cpu().numpy(); sig = a.sig.cpu().numpy()
+    hit = np.nonzero(base >= 0)[0]
+    assert (base[hit] < hit).all() and len(hit) > 100
+    for k in hit[:200]:                                                            # a base shares a whole band
+        assert any((sig[k, 32 * bnd:32 * bnd + 32] == sig[base[k], 32 * bnd:32 * bnd + 32]).all() for bnd in range(4))
+    off = a.stream_off.cpu().numpy(); out = a.streams.cpu().numpy(); kind = a.kind.cpu().numpy(); uniq = a.uniq_ids.cpu().numpy()
+    assert off[0] == 0 and off[-1] == out.size and (np.diff(off) > 0).all()
+    for k in np.concatenate([rng.integers(0, len(uniq), 400), np.nonzero(kind == 2)[0][:100]]):
+        zd = host[cuts[uniq[base[k]]]:cuts[uniq[base[k]] + 1]].tobytes() if kind[k] == 2 else None
+        d = zlib.decompressobj(-15, zdict=zd) if zd else zlib.decompressobj(-15)
+        assert d.decompress(out[off[k]:off[k + 1]].tobytes()) == host[cuts[uniq[k]]:cuts[uniq[k] + 1]].tobytes()
+        assert d.eof
+    st = ingest.merge_stats([a.stats])
+    assert st["cf"] > 2.0 and 0 < st["delta_rate"] < 1

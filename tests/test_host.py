@@ -1,0 +1,99 @@
+"""CPU: host-side logic — corpus generator, manifest records (the reference's packed structs), stats."""
+import hashlib
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_corpus_blocks_are_independent_and_deterministic():
+    from hmse_amd import corpus
+    a = corpus.wiki_synth(4 << 20, seed=42)
+    b = corpus.wiki_synth(2 << 20, seed=42, first_block=2)           # any rank can generate any block range
+    assert np.array_equal(a[2 << 20:], b)
+    assert np.array_equal(corpus.wiki_synth(1 << 20, seed=42, threads=1), a[: 1 << 20])
+    assert not np.array_equal(corpus.wiki_synth(1 << 20, seed=43), a[: 1 << 20])
+    assert a.min() >= 10 and a.max() < 128                             # ASCII text
+    r = corpus.random_bytes(4096)
+    assert np.array_equal(r, corpus.random_bytes(4096))                # seed 0xDEADBEEF (VALIDATION_METHODS.md:213)
+    for prof in ("arxiv", "news", "code"):
+        assert corpus.wiki_synth(1 << 20, profile=prof).size == 1 << 20
+
+
+def test_corpus_has_the_redundancy_profile(orc):
+    """Exact duplicates and near-duplicates exist at chunk granularity (README.md:2123-2127)."""
+    from hmse_amd import corpus
+    d = corpus.wiki_synth(48 << 20, seed=42)
+    cfg = orc.default_cfg()
+    cuts = orc.cdc(d, cfg)
+    fo, _ = orc.dedup(orc.sha256_chunks(d, cuts))
+    sz = np.diff(cuts.astype(np.int64))
+    dup_bytes = sz[fo != np.arange(len(fo))].sum() / sz.sum()
+    assert 0.01 < dup_bytes < 0.4
+    z = sum(len(zlib.compress(d[int(cuts[i]):int(cuts[i + 1])].tobytes(), 9)) for i in range(200))
+    assert sz[:200].sum() / z > 2.0                                     # README.md:2425 minimum L1 ratio
+
+
+def _shard_result_from_oracle(orc, data, cfg_kw=None):
+    from dataclasses import asdict
+    from hmse_amd import IngestConfig, ingest
+    cfg = IngestConfig(**(cfg_kw or {}))
+    oc = orc.default_cfg(**asdict(cfg))
+    cuts = orc.cdc(data, oc)
+    dg = orc.sha256_chunks(data, cuts)
+    fo, rc = orc.dedup(dg)
+    uniq = np.nonzero(fo == np.arange(len(fo)))[0].astype(np.uint64)
+    sig = orc.minhash_chunks(data, cuts, oc, uniq)
+    keys, base = orc.lsh(sig, oc)
+    out, off, kind = orc.deflate_chunks(data, cuts, oc, uniq, base)
+    t = torch.from_numpy
+    res = ingest.ShardResult(data.size, t(cuts.astype(np.int64)), t(dg), 0, len(cuts) - 1, t(fo.astype(np.int64)), t(rc.astype(np.int32)),
+                             t(uniq.astype(np.int64)), t(sig.view(np.int32)), t(keys.view(np.int32)), t(base), t(out), t(off.astype(np.int64)), t(kind))
+    res.stats = ingest.shard_stats(res)
+    return res
+
+
+def test_manifest_records_and_reconstruct(orc):
+    """ChunkIndex 40 B / DeltaChunk 8 B header / pointer 8 B (README.md:1263-1270, 2182-2189, 1312) and the
+    three-branch read path reconstructing the input bit for bit (VALIDATION_METHODS.md:257)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import corpus, manifest
+    from hmse_amd.config import KIND_DELTA, KIND_POINTER
+    data = variants_dataset(corpus.wiki_synth(3 << 20, seed=42))
+    res = _shard_result_from_oracle(orc, data, {"seg_size": 1 << 20})
+    m = manifest.build_manifest(res)
+    assert m.index.dtype.itemsize == 40 and m.pointers.dtype.itemsize == 8
+    assert len(m.index) == res.stats["unique"] and len(m.pointers) == res.stats["pointer"] > 0
+    assert (m.chunk_map["kind"] == KIND_DELTA).sum() == res.stats["delta"] > 0
+    assert (m.chunk_map["kind"] == KIND_POINTER).sum() == res.stats["pointer"]
+    e = m.index[0]
+    s0 = m.blob[int(e["lba"]) * m.lba_unit: int(e["lba"]) * m.lba_unit + int(e["length"])].tobytes()
+    assert hashlib.sha256(zlib.decompress(s0, -15)).digest() == e["sha256"].tobytes()
+    assert int(m.index["refcount"].sum()) == res.stats["chunks"]
+    blob = m.to_bytes()
+    m2 = manifest.Manifest.from_bytes(blob)
+    assert manifest.reconstruct(m2) == data.tobytes()
+    assert hashlib.sha256(manifest.reconstruct(m)).digest() == hashlib.sha256(data.tobytes()).digest()
+
+
+def test_stats_and_cf_formula(orc):
+    from hmse_amd import corpus, ingest
+    data = corpus.wiki_synth(2 << 20, seed=42)
+    res = _shard_result_from_oracle(orc, data)
+    st = ingest.merge_stats([res.stats, res.stats])
+    s = res.stats
+    assert st["bytes"] == 2 * data.size
+    # CF = N_in / (stored + 40*unique + 8*pointer + 8*delta)   (VALIDATION_METHODS.md:255)
+    assert st["cf"] == pytest.approx(data.size / (s["stored_bytes"] + 40 * s["unique"] + 8 * s["pointer"] + 8 * s["delta"]))
+    assert st["cf_payload"] > st["cf"] > 1.5
+
+
+def test_fixed_cuts_for_l1_only_ablation():
+    from hmse_amd import IngestConfig, ingest
+    cfg = IngestConfig()
+    so = torch.tensor([0, 100_000, 100_000, 170_000])
+    c = ingest.fixed_cuts(170_000, cfg, so).tolist()
+    assert c[0] == 0 and c[-1] == 170_000 and 100_000 in c and max(np.diff(c)) <= cfg.max_size
