@@ -26,6 +26,13 @@ constexpr uint32_t MINM = 4, MAXM = 258, WMAX = 32768;
 __device__ __forceinline__ uint32_t hash4(uint32_t x) { return (x * 0x9E3779B1u) >> (32 - HB); }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+// bucket cursors: two 16-bit counters per dword (values <= 65533), updated with 32-bit LDS atomics
+__device__ __forceinline__ uint32_t cur_get(const uint32_t* c, uint32_t h) { return (c[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t cur_inc(uint32_t* c, uint32_t h) {
+  const uint32_t sh = (h & 1u) * 16u;
+  return (atomicAdd(&c[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
+}
+
 // RFC 1951 §3.2.5 closed forms
 __device__ __forceinline__ void len_sym(uint32_t len, uint32_t& code, uint32_t& eb, uint32_t& ev) {
   if (len == 258) { code = 285; eb = 0; ev = 0; return; }
@@ -81,13 +88,13 @@ constexpr int align16(int v) { return (v + 15) & ~15; }
 
 // LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
 // !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
-template <int NT, int TCAP, bool LDSM>
+template <int NT, int TCAP, int LCAP_, bool LDSM>
 struct Layout {
-  static constexpr int LCAP = LDSM ? TCAP : 32768;
+  static constexpr int LCAP = LCAP_;
   static constexpr int W_OFF = 0;
   static constexpr int W_SZ = align16(TCAP + 32);
-  static constexpr int CUR_OFF = W_OFF + W_SZ;          // u32[NBK] bucket cursors; later the Huffman scratch
-  static constexpr int CUR_SZ = NBK * 4;
+  static constexpr int CUR_OFF = W_OFF + W_SZ;          // packed u16[NBK] bucket cursors; later the Huffman scratch
+  static constexpr int CUR_SZ = NBK * 2;               // two 16-bit cursors per dword
   static constexpr int MARK_OFF = CUR_OFF + CUR_SZ;
   static constexpr int MARK_SZ = align16(LCAP / 8 + 16);
   static constexpr int SMALL_OFF = MARK_OFF + MARK_SZ;
@@ -101,7 +108,7 @@ struct Layout {
   static constexpr int K_OFF = ML_OFF + ML_SZ;          // LDSM: u8 K[T] = byte 4 of the position at each sorted rank
   static constexpr int K_SZ = LDSM ? align16(TCAP + 16) : 0;
   static constexpr int TOTAL = K_OFF + K_SZ;
-  static_assert(!LDSM || MD_SZ + ML_SZ >= 2 * TCAP, "the rank-sort temporary must fit the match arrays");
+  static_assert(TOTAL <= 160 * 1024, "one workgroup's LDS image must fit the CU's 160 KiB");
   static_assert(sizeof(HuffL) + sizeof(HuffD) <= CUR_SZ, "Huffman scratch must fit the cursor table");
 };
 
@@ -320,14 +327,14 @@ __device__ __forceinline__ uint32_t slot_stride(uint32_t len) { return (len + 5 
 
 // per-workgroup global scratch of the big class
 struct Scratch {
-  uint16_t S1[65536]; uint16_t S[65536]; uint8_t K[65536 + 16];
+  uint16_t S[65536]; uint8_t K[65536 + 16];
   uint16_t jumpA[32768 + 8]; uint16_t jumpB[32768 + 8];
   uint16_t mdist[32768]; uint8_t mlen[32768];
 };
 
-template <int NT, int TCAP, bool LDSM>
+template <int NT, int TCAP, int LCAP_, bool LDSM>
 __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) {
-  using LY = Layout<NT, TCAP, LDSM>;
+  using LY = Layout<NT, TCAP, LCAP_, LDSM>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
@@ -391,61 +398,65 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
       else for (uint32_t b = i; b < L; b++) W[Dl + b] = csrc[b];
     }
     if (t < 32) W[T + t] = 0;
-    for (uint32_t i = t; i < NBK; i += NT) cur[i] = 0;
+    for (uint32_t i = t; i < NBK / 2; i += NT) cur[i] = 0;
     for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;
     for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
     if (t < 32) sm.df[t] = 0;
     if (t < 20) sm.cf[t] = 0;
     if (t == 0) sm.qhead = 0;
-    if constexpr (!LDSM) for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
+    for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
     __syncthreads();
 
     STAMP(0);
     // ---- phase 1-2: bucket histogram + exclusive scan -> bucket starts --------------------------
     const uint32_t nh = T >= 4 ? T - 3 : 0;
-    for (uint32_t q = t; q < nh; q += NT) atomicAdd(&cur[hash4(ld32(W + q))], 1u);
+    for (uint32_t q = t; q < nh; q += NT) cur_inc(cur, hash4(ld32(W + q)));
     __syncthreads();
     {
-      constexpr int PER = NBK / NT;
-      uint32_t loc[PER], sum = 0;
+      constexpr int PERW = NBK / 2 / NT > 0 ? NBK / 2 / NT : 1;  // packed words per thread
+      uint32_t wv[PERW], sum = 0;
 #pragma unroll
-      for (int i = 0; i < PER; i++) { loc[i] = cur[t * PER + i]; sum += loc[i]; }
+      for (int i = 0; i < PERW; i++) {
+        const uint32_t idx = t * PERW + i;
+        wv[i] = idx < NBK / 2 ? cur[idx] : 0u;
+        sum += (wv[i] & 0xFFFFu) + (wv[i] >> 16);
+      }
       uint32_t total;
       uint32_t ex = block_exclusive_scan<NT>(sum, sm.red, &total);
 #pragma unroll
-      for (int i = 0; i < PER; i++) { cur[t * PER + i] = ex; ex += loc[i]; }
+      for (int i = 0; i < PERW; i++) {
+        const uint32_t idx = t * PERW + i;
+        const uint32_t lo16 = ex; ex += wv[i] & 0xFFFFu;
+        const uint32_t hi16 = ex; ex += wv[i] >> 16;
+        if (idx < NBK / 2) cur[idx] = lo16 | (hi16 << 16);
+      }
     }
     __syncthreads();
     STAMP(1);
     // ---- phase 3-4: scatter, then rank inside the bucket -> ascending positions -------------------
     {
-      // Counting sort with ORDERED buckets.  Positions are scattered NT at a time in ascending order
-      // (two barriers per step), so bucket contents are already ordered between steps; inside one step
-      // the same-hash positions land in the contiguous slot range [before, after) of their bucket in
-      // arbitrary order and are ranked there (ranges hold a handful of entries: the quadratic rank is
-      // over the step's duplicates only, not over the whole bucket).
-      uint16_t* const S1 = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->S1;  // staging (match arrays, not yet in use)
+      // Counting sort with ORDERED buckets, in place.  Positions are scattered NT at a time in ascending
+      // order, so bucket contents are already ordered between steps; inside one step the same-hash
+      // positions land in the contiguous slot range [before, after) of their bucket in arbitrary order
+      // and are ranked there (a handful of entries: the quadratic rank is over the step's duplicates
+      // only, not over the whole bucket).  Three barriers per step.
       for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
         const uint32_t q = q0 + t;
         const bool act = q < nh;
         uint32_t h = 0, before = 0;
-        if (act) { h = hash4(ld32(W + q)); before = cur[h]; }
+        if (act) { h = hash4(ld32(W + q)); before = cur_get(cur, h); }
         __syncthreads();
-        if (act) S1[atomicAdd(&cur[h], 1u)] = (uint16_t)q;
+        if (act) S[cur_inc(cur, h)] = (uint16_t)q;
         __syncthreads();
+        uint32_t r = 0;
         if (act) {
-          const uint32_t after = cur[h];
-          uint32_t r = 0;
-          for (uint32_t jj = before; jj < after; jj++) r += S1[jj] < q;
-          S[before + r] = (uint16_t)q;
-          K[before + r] = W[q + 4];
+          const uint32_t after = cur_get(cur, h);
+          for (uint32_t jj = before; jj < after; jj++) r += S[jj] < q;
         }
-      }
-      __syncthreads();  // cur[h] now = end of bucket h
-      if constexpr (LDSM) {  // the staging area overlapped mlen/mdist: clear mlen now
-        for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
         __syncthreads();
+        if (act) { S[before + r] = (uint16_t)q; K[before + r] = W[q + 4]; }
       }
+      __syncthreads();  // cursor h now = end of bucket h
     }
     STAMP(2);
     // ---- phase 5: longest match for every chunk position ----------------------------------------
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
                 qn = i ? S[i - 1] : 0u; kn = i ? K[i - 1] : 0u;  // first candidate (used iff kmax != 0)
                 pw0 = ld32(W + p); pw1 = ld32(W + p + 4);
                 const uint32_t h = hash4(pw0);
-                const uint32_t lo = h ? cur[h - 1] : 0u;
+                const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
                 maxlen = (T - p) < MAXM ? (T - p) : MAXM;
                 kmax = i - lo;
                 if (kmax > a.depth) kmax = a.depth;
@@ -770,11 +781,16 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
 #endif
 }
 
-// size classes: everything in LDS for T <= 8192 (two workgroups per CU) and T <= 18432 (one per CU);
-// larger windows (up to 32 KiB chunk + 32 KiB dictionary) keep their per-position arrays in global scratch
-constexpr int NT_S = 512, TCAP_S = 8192;
-constexpr int NT_M = 1024, TCAP_M = 18432;
-constexpr int NT_B = 512, TCAP_B = 65536;
+// Size classes (window T = dictionary + chunk, chunk L).  Every per-position array is in LDS for
+//   S : T <= 9216                 (79 KiB  -> two workgroups per CU)
+//   MF: T <= 20480                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
+//   MD: T <= 26624 and L <= 13312 (161 KiB -> one per CU; chunk + full dictionary)
+// and larger windows (up to 32 KiB + 32 KiB) keep them in a per-workgroup global scratch (B).
+constexpr int NT_S = 512, TCAP_S = 9216;
+constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
+constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
+constexpr int N_CLASS = 4;
+static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
@@ -784,7 +800,9 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   if (k >= n_sel) return;
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
   const uint64_t L = cuts[c + 1] - cuts[c];
-  auto cls = [](uint64_t T) -> uint32_t { return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_M ? 1u : 2u; };
+  auto cls = [L](uint64_t T) -> uint32_t {
+    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_MF ? 1u : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
+  };
   {
     const uint32_t cl = cls(L);
     lists[cl * list_stride + atomicAdd(&counts[cl], 1u)] = (uint32_t)(k << 1);
@@ -912,7 +930,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 128;  // persistent workgroups of the big class (global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..2] job counts per class, [4..6] job cursors
+  uint32_t* counters;  // [0..3] job counts per class, [4..7] job cursors
   uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
   uint8_t* scratch; uint8_t* slots; size_t fixed_bytes;
@@ -928,23 +946,23 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.len_full = w.take<uint32_t>(n_sel);
   r.len_delta = w.take<uint32_t>(n_sel);
   r.list_stride = 2 * n_sel;
-  r.lists = w.take<uint32_t>(3 * r.list_stride);
+  r.lists = w.take<uint32_t>(N_CLASS * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
   r.fixed_bytes = w.off;
   r.slots = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
 }
 
-template <int NT, int TCAP, bool LDSM>
+template <int NT, int TCAP, int LCAP, bool LDSM>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
-  using LY = Layout<NT, TCAP, LDSM>;
+  using LY = Layout<NT, TCAP, LCAP, LDSM>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LDSM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
       return HMSE_EHIP;
     attr_set = true;
   }
-  l1_deflate_kernel<NT, TCAP, LDSM><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  l1_deflate_kernel<NT, TCAP, LCAP, LDSM><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -994,12 +1012,15 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;
   PROF_BEGIN(HMSE_STAGE_L1_DEFLATE, stream);
-  a.jobs = w.lists; a.n_jobs = w.counters + 0; a.counter = w.counters + 4;
-  if (launch_class<NT_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  a.jobs = w.lists + w.list_stride; a.n_jobs = w.counters + 1; a.counter = w.counters + 5;
-  if (launch_class<NT_M, TCAP_M, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  // big windows first (few, long jobs), then the LDS classes
+  a.jobs = w.lists + 3 * w.list_stride; a.n_jobs = w.counters + 3; a.counter = w.counters + 7;
+  if (launch_class<NT_B, TCAP_B, LCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
   a.jobs = w.lists + 2 * w.list_stride; a.n_jobs = w.counters + 2; a.counter = w.counters + 6;
-  if (launch_class<NT_B, TCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
+  if (launch_class<NT_M, TCAP_MD, LCAP_MD, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  a.jobs = w.lists + w.list_stride; a.n_jobs = w.counters + 1; a.counter = w.counters + 5;
+  if (launch_class<NT_M, TCAP_MF, TCAP_MF, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  a.jobs = w.lists; a.n_jobs = w.counters + 0; a.counter = w.counters + 4;
+  if (launch_class<NT_S, TCAP_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(HMSE_STAGE_L1_DEFLATE, stream);
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status);

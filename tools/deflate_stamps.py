@@ -28,6 +28,17 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
 lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
 names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch"]
+lens = (cuts[1:] - cuts[:-1])[uniq]
+hb = base >= 0
+Tfull = lens
+Tdelta = (lens + torch.clamp(lens[base.clamp(min=0)], max=32768))[hb]
+allT = torch.cat([Tfull, Tdelta]).cpu().numpy()
+allL = torch.cat([lens, lens[hb]]).cpu().numpy()
+import numpy as _np
+cls_ = _np.where(allT <= 9216, 0, _np.where(allT <= 20480, 1, _np.where((allT <= 26624) & (allL <= 13312), 2, 3)))
+for ci_, nm in enumerate(("S", "MF", "MD", "B")):
+    m_ = cls_ == ci_
+    print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
 for c, cn in enumerate(["small", "medium", "big"]):
     row = buf[c * 16:(c + 1) * 16].astype(np.float64)
