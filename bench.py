@@ -24,7 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel", 7: "l1_deflate_kernel"}
+STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
+               8: "l1_deflate_kernel<512,9216,9216,true,false>", 9: "l1_deflate_kernel<1024,20480,20480,true,false>",
+               10: "l1_deflate_kernel<1024,26624,13312,true,false>", 11: "l1_deflate_kernel<512,65536,32768,false,false>",
+               12: "l1_deflate_kernel<512,12288,12288,true,true>"}
+DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12}  # size classes S, MF, MD, B, S2 (hmse_amd/csrc/l1_deflate.hip)
 
 
 def parse():
@@ -85,6 +89,20 @@ def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
             "seconds": round(dt, 2), "cf_payload_zlib9": nbytes / max(1, sum(r[1] for r in res))}
 
 
+def measured_traffic(kernel: str, total_bytes: int, world: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+    note of MI355X_MICROARCH.md, + WRITE_SIZE), valid only for the workload they were taken on; else None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        e = t["kernels"][kernel]
+        if world == 1 and t["total_bytes"] == total_bytes:
+            return {"hbm_bytes": e["hbm_bytes"], "GB": round(e["hbm_bytes"] / 1e9, 3), "source": t["source"]}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -131,7 +149,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    res = None
     for _ in range(a.warmup):
+        res = None  # free the previous step's outputs first: the caching allocator then reuses them
         res = step()
     lib.hmse_profile_enable(1)
     for s in STAGE_NAMES:
@@ -139,6 +159,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        res = None
         res = step()
     barrier()
     dt = time.perf_counter() - t0
@@ -164,14 +185,28 @@ def main():
         hb = res.base >= 0
         dict_bytes = int(lens[res.uniq_ids[res.base[hb]]].sum().item()) if bool(hb.any()) else 0
     alg = {"l2_hash_kernel": n_local, "l3_sha256_kernel": n_local + 32 * st["chunks"],
-           "l4_minhash_kernel": st["unique_bytes"] + 512 * st["unique"],
-           "l1_deflate_kernel": st["unique_bytes"] + dict_bytes + st["stored_bytes"]}
+           "l4_minhash_kernel": st["unique_bytes"] + 512 * st["unique"]}
+    # DEFLATE jobs per size class: window bytes read (chunk + dictionary) + the share of stream bytes written
+    if res.kind is not None and res.uniq_ids.numel():
+        ul = lens[res.uniq_ids]
+        hb = res.base >= 0 if res.base is not None else torch.zeros_like(ul, dtype=torch.bool)
+        dl = torch.clamp(ul[res.base.clamp(min=0)], max=32768) if res.base is not None else torch.zeros_like(ul)
+        jobs_T = torch.cat([ul, (ul + dl)[hb]])
+        jobs_L = torch.cat([ul, ul[hb]])
+        cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 20480, 1,
+                          torch.where((jobs_T <= 26624) & (jobs_L <= 13312), 2, 3))))
+        cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
+        for c, slot in DEFLATE_CLASS_SLOT.items():
+            m = cls == c
+            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + jobs_L[m].sum().item() / cf_l1)
     stage_roof = {}
     for name, k in kern.items():
+        if name not in alg:
+            continue
         gbps = alg[name] / (k["avg_ms"] * 1e-3) / 1e9
         stage_roof[name] = {"avg_ms": round(k["avg_ms"], 4), "alg_bytes": int(alg[name]), "GBps": round(gbps, 2),
                             "frac_hbm": round(gbps / HBM_PEAK_GBPS, 5)}
-    dom = max(kern, key=lambda nme: kern[nme]["avg_ms"]) if kern else None
+    dom = max(stage_roof, key=lambda nme: stage_roof[nme]["avg_ms"]) if stage_roof else None
 
     stats = [st]
     if distributed:
@@ -198,7 +233,7 @@ def main():
         if dom:
             r = stage_roof[dom]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": r["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": r["frac_hbm"], "traffic": None,
+                               "frac": r["frac_hbm"], "traffic": measured_traffic(dom, tot["bytes"], world),
                                "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0"}
         out["stage_roofline"] = stage_roof
         if not a.no_cpu_baseline and world == 1:

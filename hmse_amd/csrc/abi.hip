@@ -97,7 +97,7 @@ int g_hmse_prof = 0;
 namespace {
 constexpr int PROF_RING = 64;
 struct ProfStage { hipEvent_t e0[PROF_RING], e1[PROF_RING]; int n = 0; bool init = false; double ms = 0; uint64_t launches = 0; };
-ProfStage g_ps[8];
+ProfStage g_ps[16];
 void prof_flush(ProfStage& p) {
   for (int i = 0; i < p.n; i++) {
     float t = 0;
@@ -107,19 +107,19 @@ void prof_flush(ProfStage& p) {
 }
 }  // namespace
 void hmse_prof_begin(int stage, hipStream_t s) {
-  ProfStage& p = g_ps[stage & 7];
+  ProfStage& p = g_ps[stage & 15];
   if (!p.init) { for (int i = 0; i < PROF_RING; i++) { (void)hipEventCreate(&p.e0[i]); (void)hipEventCreate(&p.e1[i]); } p.init = true; }
   if (p.n == PROF_RING) prof_flush(p);
   (void)hipEventRecord(p.e0[p.n], s);
 }
 void hmse_prof_end(int stage, hipStream_t s) {
-  ProfStage& p = g_ps[stage & 7];
+  ProfStage& p = g_ps[stage & 15];
   (void)hipEventRecord(p.e1[p.n], s);
   p.n++;
 }
 extern "C" void hmse_profile_enable(int on) { g_hmse_prof = on; }
 extern "C" int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset) {
-  if (stage < 0 || stage > 7) return HMSE_EINVAL;
+  if (stage < 0 || stage > 15) return HMSE_EINVAL;
   ProfStage& p = g_ps[stage];
   prof_flush(p);
   if (total_ms) *total_ms = p.ms;

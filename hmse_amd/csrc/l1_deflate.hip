@@ -88,7 +88,7 @@ constexpr int align16(int v) { return (v + 15) & ~15; }
 
 // LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
 // !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
-template <int NT, int TCAP, int LCAP_, bool LDSM>
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false>
 struct Layout {
   static constexpr int LCAP = LCAP_;
   static constexpr int W_OFF = 0;
@@ -102,7 +102,7 @@ struct Layout {
   static constexpr int A_OFF = SMALL_OFF + SMALL_SZ;    // LDSM: u16 S[T] -> u16 jump[L+1] -> out image; !LDSM: out image
   static constexpr int A_SZ = LDSM ? align16(2 * TCAP + 80) : align16(LCAP + 80);
   static constexpr int MD_OFF = A_OFF + A_SZ;           // LDSM: u16 mdist[L]
-  static constexpr int MD_SZ = LDSM ? align16(2 * LCAP) : 0;
+  static constexpr int MD_SZ = (LDSM && !MDG) ? align16(2 * LCAP) : 0;
   static constexpr int ML_OFF = MD_OFF + MD_SZ;         // LDSM: u8 mlen[L]
   static constexpr int ML_SZ = LDSM ? align16(LCAP) : 0;
   static constexpr int K_OFF = ML_OFF + ML_SZ;          // LDSM: u8 K[T] = byte 4 of the position at each sorted rank
@@ -332,9 +332,9 @@ struct Scratch {
   uint16_t mdist[32768]; uint8_t mlen[32768];
 };
 
-template <int NT, int TCAP, int LCAP_, bool LDSM>
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false>
 __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) {
-  using LY = Layout<NT, TCAP, LCAP_, LDSM>;
+  using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
@@ -345,9 +345,12 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
   Small<NT>& sm = *(Small<NT>*)(smem + LY::SMALL_OFF);
   uint32_t* const out = (uint32_t*)(smem + LY::A_OFF);
   Scratch* const sc = LDSM ? nullptr : (Scratch*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
+  // class S2 keeps only the match distances in a small per-workgroup global array (written once per match,
+  // read once per emitted match), which lets a 12 KiB window fit twice per CU
+  uint16_t* const mdist_g = MDG ? (uint16_t*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride) : nullptr;
   uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
   uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
-  uint16_t* const mdist = LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
+  uint16_t* const mdist = MDG ? mdist_g : LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
   uint8_t* const mlen = LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
   uint8_t* const K = LDSM ? (uint8_t*)(smem + LY::K_OFF) : sc->K;
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
@@ -783,37 +786,53 @@ __global__ __launch_bounds__(NT, (LDSM ? 4 : 2)) void l1_deflate_kernel(Args a) 
 
 // Size classes (window T = dictionary + chunk, chunk L).  Every per-position array is in LDS for
 //   S : T <= 9216                 (79 KiB  -> two workgroups per CU)
+//   S2: T <= 12288                (76 KiB  -> two per CU; match distances in a small global array)
 //   MF: T <= 20480                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
 //   MD: T <= 26624 and L <= 13312 (161 KiB -> one per CU; chunk + full dictionary)
 // and larger windows (up to 32 KiB + 32 KiB) keep them in a per-workgroup global scratch (B).
-constexpr int NT_S = 512, TCAP_S = 9216;
+constexpr int NT_S = 512, TCAP_S = 9216, TCAP_S2 = 12288;
 constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_CLASS = 4;
+constexpr int N_CLASS = 5;
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
+static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
 
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel,
                                                         uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_sel) return;
-  const uint64_t c = chunk_ids ? chunk_ids[k] : k;
-  const uint64_t L = cuts[c + 1] - cuts[c];
-  auto cls = [L](uint64_t T) -> uint32_t {
-    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_MF ? 1u : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
+  // wave-aggregated append (one atomic per class per wavefront instead of one per job)
+  auto append = [&](bool on, uint32_t cl, uint32_t job) {
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)N_CLASS; c++) {
+      const uint64_t m = __ballot(on && cl == c);
+      if (m == 0) continue;
+      uint32_t base0 = 0;
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      if (lane_id() == leader) base0 = atomicAdd(&counts[c], (uint32_t)__builtin_popcountll(m));
+      base0 = (uint32_t)__builtin_amdgcn_readlane((int)base0, (int)leader);
+      if (on && cl == c) lists[(size_t)c * list_stride + base0 + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = job;
+    }
   };
-  {
-    const uint32_t cl = cls(L);
-    lists[cl * list_stride + atomicAdd(&counts[cl], 1u)] = (uint32_t)(k << 1);
+  const bool in = k < n_sel;
+  uint64_t L = 0; bool hasb = false; uint64_t Dl = 0;
+  if (in) {
+    const uint64_t c = chunk_ids ? chunk_ids[k] : k;
+    L = cuts[c + 1] - cuts[c];
+    if (base && base[k] >= 0) {
+      const uint64_t bc = chunk_ids ? chunk_ids[base[k]] : (uint64_t)base[k];
+      Dl = cuts[bc + 1] - cuts[bc];
+      if (Dl > WMAX) Dl = WMAX;
+      hasb = true;
+    }
   }
-  if (base && base[k] >= 0) {
-    const uint64_t bc = chunk_ids ? chunk_ids[base[k]] : (uint64_t)base[k];
-    uint64_t Dl = cuts[bc + 1] - cuts[bc];
-    if (Dl > WMAX) Dl = WMAX;
-    const uint32_t cl = cls(L + Dl);
-    lists[cl * list_stride + atomicAdd(&counts[cl], 1u)] = (uint32_t)((k << 1) | 1u);
-  }
+  auto cls = [&](uint64_t T) -> uint32_t {
+    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_MF ? 1u
+           : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
+  };
+  append(in, cls(L), (uint32_t)(k << 1));
+  append(in && hasb, cls(L + Dl), (uint32_t)((k << 1) | 1u));
 }
 
 // slot sizes: FULL (+ DELTA when a base exists), 16-byte aligned; also clears the lengths
@@ -930,10 +949,10 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 128;  // persistent workgroups of the big class (global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..3] job counts per class, [4..7] job cursors
+  uint32_t* counters;  // [0..4] job counts per class, [8..12] job cursors
   uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
-  uint8_t* scratch; uint8_t* slots; size_t fixed_bytes;
+  uint8_t* scratch; uint8_t* scratch2; uint8_t* slots; size_t fixed_bytes;
 };
 static Ws carve(void* ws, uint64_t n_sel) {
   WsCarver w(ws, ~(size_t)0);
@@ -948,21 +967,22 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.list_stride = 2 * n_sel;
   r.lists = w.take<uint32_t>(N_CLASS * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
+  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(2 * TCAP_S2, 256));
   r.fixed_bytes = w.off;
   r.slots = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
 }
 
-template <int NT, int TCAP, int LCAP, bool LDSM>
+template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
-  using LY = Layout<NT, TCAP, LCAP, LDSM>;
+  using LY = Layout<NT, TCAP, LCAP, LDSM, MDG>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
       return HMSE_EHIP;
     attr_set = true;
   }
-  l1_deflate_kernel<NT, TCAP, LCAP, LDSM><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -1011,17 +1031,29 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;
-  PROF_BEGIN(HMSE_STAGE_L1_DEFLATE, stream);
   // big windows first (few, long jobs), then the LDS classes
-  a.jobs = w.lists + 3 * w.list_stride; a.n_jobs = w.counters + 3; a.counter = w.counters + 7;
+  auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 8 + c; };
+  sel(3);
+  PROF_BEGIN(8 + 3, stream);
   if (launch_class<NT_B, TCAP_B, LCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
-  a.jobs = w.lists + 2 * w.list_stride; a.n_jobs = w.counters + 2; a.counter = w.counters + 6;
+  PROF_END(8 + 3, stream);
+  sel(2);
+  PROF_BEGIN(8 + 2, stream);
   if (launch_class<NT_M, TCAP_MD, LCAP_MD, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
-  a.jobs = w.lists + w.list_stride; a.n_jobs = w.counters + 1; a.counter = w.counters + 5;
+  PROF_END(8 + 2, stream);
+  sel(1);
+  PROF_BEGIN(8 + 1, stream);
   if (launch_class<NT_M, TCAP_MF, TCAP_MF, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
-  a.jobs = w.lists; a.n_jobs = w.counters + 0; a.counter = w.counters + 4;
+  PROF_END(8 + 1, stream);
+  sel(4);
+  a.scratch = w.scratch2; a.scratch_stride = hmse_align_up(2 * TCAP_S2, 256);
+  PROF_BEGIN(8 + 4, stream);
+  if (launch_class<NT_S, TCAP_S2, TCAP_S2, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
+  PROF_END(8 + 4, stream);
+  sel(0);
+  PROF_BEGIN(8 + 0, stream);
   if (launch_class<NT_S, TCAP_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(HMSE_STAGE_L1_DEFLATE, stream);
+  PROF_END(8 + 0, stream);
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status);
   HMSE_LAUNCH_CHECK();

@@ -19,6 +19,9 @@ __constant__ uint32_t kK256[64] = {
     0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
     0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
+// 3-input xor in one VALU op (v_bitop3_b32, truth table 0x96)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 __device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
   uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
@@ -28,16 +31,16 @@ __device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) 
       wi = w[i];
     } else {
       const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-      const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-      const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+      const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
       wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
       w[i & 15] = wi;
     }
-    const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-    const uint32_t ch = (e & f) | (~e & g);  // -> v_bfi_b32
+    const uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+    const uint32_t ch = (uint32_t)__builtin_amdgcn_bitop3_b32(e, f, g, 0xCA);  // e ? f : g
     const uint32_t t1 = h + S1 + ch + kK256[i] + wi;
-    const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-    const uint32_t mj = (a & b) | (c & (a | b));
+    const uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+    const uint32_t mj = (uint32_t)__builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);  // majority
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + S0 + mj;
   }
   st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
@@ -52,6 +55,8 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
   uint32_t rem = 0;       // message bytes not yet consumed
   uint32_t phase = 3;     // 0 data blocks, 1 pad-only block pending, 3 idle (needs a chunk), 4 retired
   uint32_t st[8];
+  uint64_t nx_addr = ~0ull;  // address of the prefetched block (none)
+  uint4 nx0 = make_uint4(0, 0, 0, 0), nx1 = nx0, nx2 = nx0, nx3 = nx0;
   for (;;) {
     // ---- refill idle lanes (wave-aggregated fetch-add) ----
     const uint64_t need = __ballot(phase == 3);
@@ -79,7 +84,10 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
     uint32_t w[16];
     bool last;
     if (phase == 0) {
-      if (cur + 64 <= n) {
+      if (nx_addr == cur) {  // block prefetched during the previous compression
+        w[0] = nx0.x; w[1] = nx0.y; w[2] = nx0.z; w[3] = nx0.w; w[4] = nx1.x; w[5] = nx1.y; w[6] = nx1.z; w[7] = nx1.w;
+        w[8] = nx2.x; w[9] = nx2.y; w[10] = nx2.z; w[11] = nx2.w; w[12] = nx3.x; w[13] = nx3.y; w[14] = nx3.z; w[15] = nx3.w;
+      } else if (cur + 64 <= n) {
         const uint4 v0 = load_u4_unaligned(data + cur), v1 = load_u4_unaligned(data + cur + 16);
         const uint4 v2 = load_u4_unaligned(data + cur + 32), v3 = load_u4_unaligned(data + cur + 48);
         w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
@@ -95,6 +103,12 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
           }
           w[i] = x;
         }
+      }
+      // prefetch the following block of this chunk; its latency hides under the 64 rounds below
+      if (rem > 64 && cur + 128 <= n) {
+        nx_addr = cur + 64;
+        nx0 = load_u4_unaligned(data + nx_addr); nx1 = load_u4_unaligned(data + nx_addr + 16);
+        nx2 = load_u4_unaligned(data + nx_addr + 32); nx3 = load_u4_unaligned(data + nx_addr + 48);
       }
 #pragma unroll
       for (int i = 0; i < 16; i++) w[i] = __builtin_bswap32(w[i]);
@@ -148,9 +162,11 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
-  // persistent grid: enough lanes to cover the chunks, at most 8 workgroups of 256 per CU (256 CUs)
+  // persistent grid: one chunk per lane while chunks are scarce (the longest chunk bounds the run time
+  // anyway), capped at 4 workgroups of 256 per CU (4 waves per SIMD saturate the VALU) so that on large
+  // inputs every lane hashes several chunks and the dynamic hand-out evens out the 2..32 KiB length skew
   uint64_t blocks = (n_chunks + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   PROF_BEGIN(HMSE_STAGE_L3_SHA256, stream);
   l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws);
   PROF_END(HMSE_STAGE_L3_SHA256, stream);

@@ -178,6 +178,8 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
  * kernel launch with a HIP event pair on the caller's stream.  hmse_profile_read() waits for the
  * recorded events (a host sync — never call it inside a capture), adds their durations to the
  * stage's running total and returns it.  Off by default; not part of the data path.
+ * Slots: the HMSE_STAGE_* ids; the five DEFLATE size-class kernels report in slots 8..12
+ * (S, MF, MD, B, S2 — see hmse_amd/csrc/l1_deflate.hip).
  */
 void hmse_profile_enable(int on);
 int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset);

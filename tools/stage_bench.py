@@ -25,8 +25,9 @@ def main():
     ap.add_argument("--mib", type=int, default=1024)
     ap.add_argument("--stages", default="l2,l3,dedup,l4,lsh,l1")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=0)
     a = ap.parse_args()
-    cfg = IngestConfig()
+    cfg = IngestConfig(chain_depth=a.depth)
     n = a.mib << 20
     t0 = time.time(); host = corpus.wiki_synth(n); tg = time.time() - t0
     dev = torch.device("cuda:0")
