@@ -946,7 +946,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
-constexpr int N_WG_B = 128;  // persistent workgroups of the big class (global scratch each)
+constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per CU, global scratch each)
 
 struct Ws {
   uint32_t* counters;  // [0..4] job counts per class, [8..12] job cursors
