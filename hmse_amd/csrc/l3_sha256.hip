@@ -48,7 +48,8 @@ __device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) 
 
 __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                          const uint64_t* __restrict__ cuts, uint64_t n_chunks,
-                                                         uint8_t* __restrict__ digests, unsigned long long* counter) {
+                                                         uint8_t* __restrict__ digests, unsigned long long* counter,
+                                                         const uint32_t* __restrict__ order) {
   const uint32_t lane = lane_id();
   // per-lane chunk state
   uint64_t idx = 0, cur = 0, len = 0;
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
       if (lane == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(need));
       base = __shfl(base, leader, 64);
       if (phase == 3) {
-        idx = base + (uint64_t)__builtin_popcountll(need & lanemask_lt());
-        if (idx < n_chunks) {
+        const uint64_t slot = base + (uint64_t)__builtin_popcountll(need & lanemask_lt());
+        if (slot < n_chunks) {
+          idx = order ? (uint64_t)order[slot] : slot;  // longest chunks are handed out first
           const uint64_t c0 = cuts[idx], c1 = cuts[idx + 1];
           cur = c0; len = c1 - c0; rem = (uint32_t)len; phase = 0;
           st[0] = 0x6a09e667; st[1] = 0xbb67ae85; st[2] = 0x3c6ef372; st[3] = 0xa54ff53a;
@@ -152,23 +154,68 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
   }
 }
 
-size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t) { return 256; }
+// ---- hand-out order: chunks sorted by descending block count (counting sort, 1024 bins) -----------------
+// Lanes hash one chunk each, so a wavefront runs as long as its longest chunk.  Handing chunks out longest
+// first gives every wavefront 64 chunks of (nearly) equal length and leaves the short ones for the end,
+// where they even out the finish times (longest-processing-time-first scheduling).
+constexpr uint32_t ORD_BINS = 1024;
+__device__ __forceinline__ uint32_t ord_key(uint64_t len) {
+  const uint64_t nb = (len + 9 + 63) / 64;
+  return ORD_BINS - 1 - (uint32_t)(nb < ORD_BINS - 1 ? nb : ORD_BINS - 1);  // descending length
+}
+__global__ __launch_bounds__(256) void ord_hist_kernel(const uint64_t* __restrict__ cuts, uint64_t n, uint32_t* __restrict__ bins) {
+  __shared__ uint32_t s_bins[ORD_BINS];
+  for (uint32_t i = threadIdx.x; i < ORD_BINS; i += 256) s_bins[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    atomicAdd(&s_bins[ord_key(cuts[i + 1] - cuts[i])], 1u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ORD_BINS; i += 256) if (s_bins[i]) atomicAdd(&bins[i], s_bins[i]);
+}
+__global__ __launch_bounds__(ORD_BINS) void ord_scan_kernel(uint32_t* __restrict__ bins) {
+  __shared__ uint32_t s_red[ORD_BINS / 64 + 1];
+  uint32_t total;
+  const uint32_t v = bins[threadIdx.x];
+  bins[threadIdx.x] = block_exclusive_scan<ORD_BINS>(v, s_red, &total);
+}
+__global__ __launch_bounds__(256) void ord_scatter_kernel(const uint64_t* __restrict__ cuts, uint64_t n, uint32_t* __restrict__ bins,
+                                                           uint32_t* __restrict__ order) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) order[atomicAdd(&bins[ord_key(cuts[i + 1] - cuts[i])], 1u)] = (uint32_t)i;
+}
+
+size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t n_chunks) { return 256 + ORD_BINS * 4 + hmse_align_up((size_t)n_chunks * 4, 256); }
 
 extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* cuts, uint64_t n_chunks, uint8_t* digests,
                               void* ws, size_t ws_bytes, void* stream_) {
   if (n_chunks == 0) return HMSE_OK;
   if (!data || !cuts || !digests) return HMSE_EINVAL;
   if (!ws || ws_bytes < 8) return HMSE_ENOSPC;
+  if (n_chunks >= 0xFFFFFFFFull) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
-  HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
+  // with enough workspace (hmse_workspace_bytes) chunks are handed out longest first; otherwise in index order
+  uint32_t* bins = (uint32_t*)((uint8_t*)ws + 256);
+  uint32_t* order = nullptr;
+  if (ws_bytes >= hmse_l3_sha256_workspace_bytes_impl(n_chunks) && n_chunks > 4096) {
+    order = bins + ORD_BINS;
+    HMSE_HIP(hipMemsetAsync(ws, 0, 256 + ORD_BINS * 4, stream));
+    uint64_t hb = (n_chunks + 255) / 256;
+    if (hb > 1024) hb = 1024;
+    ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts, n_chunks, bins);
+    ord_scan_kernel<<<dim3(1), dim3(ORD_BINS), 0, stream>>>(bins);
+    ord_scatter_kernel<<<dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts, n_chunks, bins, order);
+    HMSE_LAUNCH_CHECK();
+  } else {
+    HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
+  }
   // persistent grid: one chunk per lane while chunks are scarce (the longest chunk bounds the run time
   // anyway), capped at 4 workgroups of 256 per CU (4 waves per SIMD saturate the VALU) so that on large
   // inputs every lane hashes several chunks and the dynamic hand-out evens out the 2..32 KiB length skew
   uint64_t blocks = (n_chunks + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   PROF_BEGIN(HMSE_STAGE_L3_SHA256, stream);
-  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws);
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws, order);
   PROF_END(HMSE_STAGE_L3_SHA256, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;

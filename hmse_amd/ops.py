@@ -93,7 +93,7 @@ def l3_sha256(data: torch.Tensor, cuts: torch.Tensor) -> torch.Tensor:
     out = torch.empty((max(n_chunks, 0), 32), dtype=torch.uint8, device=data.device)
     if n_chunks <= 0:
         return out
-    ws = _ws(256, data.device)
+    ws = _ws(workspace_bytes(STAGE_SHA, n_chunks, IngestConfig()), data.device)
     rc = _lib.hip_lib().hmse_l3_sha256(_ptr(data), data.numel(), _ptr(cuts), n_chunks, _ptr(out), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_l3_sha256")
     return out
