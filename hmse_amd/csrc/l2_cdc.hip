@@ -3,9 +3,12 @@
 // Replaces rabin_slide() + the cut loop of the reference skeleton (README.md:2456-2464,
 // 2475-2490).  Because the rolling state is never reset at a cut, "byte i
 // is a cut candidate" is a pure function of the 64 bytes ending at i, so the work splits into
-//   (1) l2_hash_kernel   — HBM-bound scan: coalesced 16-B loads into a padded LDS tile, one
-//                          strip per lane, Gear table replicated in LDS, candidate bitmaps in
-//                          registers, wavefront prefix-scan compaction into a sorted list;
+//   (1) l2_hash_kernel   — HBM-bound scan: one 128-byte strip per lane loaded with 16-byte loads
+//                          (each cache line is consumed whole by its lane), 64-byte warm-up, Gear
+//                          table in LDS, one v_min per byte into a running minimum (hits are
+//                          located only in the rare 16-byte group whose minimum is below the
+//                          threshold), candidate bitmaps in registers, wavefront prefix-scan
+//                          compaction into a sorted list;
 //   (2) l2_resolve_kernel — per segment, one wavefront walks the sorted candidates with
 //                          ballots applying MIN / two-mask normalisation / MAX;
 //   (3) l2_scan/l2_copy  — concatenate the per-segment cut lists.
@@ -32,10 +35,22 @@ extern "C" void hmse_gear_table(uint64_t table[256]) { memcpy(table, kGearHost.v
 
 // ---- geometry ---------------------------------------------------------------------------------
 constexpr int L2_NT = 256;                     // threads per workgroup
-constexpr int L2_STRIP = 128;                  // bytes per lane
+#ifndef HMSE_L2_STRIP
+#define HMSE_L2_STRIP 128
+#endif
+#ifndef HMSE_L2_COPIES
+#define HMSE_L2_COPIES 4
+#endif
+// Two data paths were measured (tools/l2_sweep.py, 4 GiB): tile staged in LDS (define HMSE_L2_STAGED;
+// 2.17 TB/s with one table copy, LDS-capacity-limited to 16 waves/CU) and direct per-lane strip loads
+// (default; 2.29 TB/s, 28 waves/CU).
+#ifndef HMSE_L2_STAGED
+#define HMSE_L2_DIRECT 1
+#endif
+constexpr int L2_STRIP = HMSE_L2_STRIP;          // bytes per lane
 constexpr int L2_TILE = L2_NT * L2_STRIP;      // 32 KiB of input per workgroup
 constexpr int L2_PSTRIDE = L2_STRIP + 16;      // padded strip pitch: ds_read_b128 conflict-free
-constexpr int L2_COPIES = 8;                   // Gear table replicas (bank spreading)
+constexpr int L2_COPIES = HMSE_L2_COPIES;        // Gear table replicas: 1 measured best (occupancy beats bank spreading)
 constexpr int L2_WORDS = L2_STRIP / 32;        // bitmap dwords per lane
 
 struct TileInfo { unsigned long long base; uint32_t count; uint32_t pad; };
@@ -48,10 +63,12 @@ __device__ __forceinline__ uint64_t gear_lookup(const uint64_t* lg, uint32_t byt
 }
 
 __global__ __launch_bounds__(L2_NT) void l2_hash_kernel(const uint8_t* __restrict__ data, uint64_t n,
-                                                          uint32_t ml_hi, uint32_t ms_hi,
+                                                          uint32_t thr_l, uint32_t thr_s,
                                                           uint32_t* __restrict__ cand, uint64_t cand_cap,
                                                           TileInfo* __restrict__ tinfo, L2Header* hdr) {
+#ifndef HMSE_L2_DIRECT
   __shared__ __attribute__((aligned(16))) uint8_t s_data[(L2_NT + 1) * L2_PSTRIDE];
+#endif
   __shared__ uint64_t s_gear[256 * L2_COPIES];
   __shared__ uint32_t s_red[L2_NT / 64 + 1];
   __shared__ unsigned long long s_base;
@@ -64,6 +81,35 @@ __global__ __launch_bounds__(L2_NT) void l2_hash_kernel(const uint8_t* __restric
 #pragma unroll
   for (int c = 0; c < L2_COPIES; c++) s_gear[t * L2_COPIES + c] = kGearDev.v[t];
 
+#ifdef HMSE_L2_DIRECT
+  // Direct variant: every lane loads its own strip (plus the 64 bytes in front of it) straight into
+  // registers with 16-byte loads.  A wave-instruction touches 64 different cache lines, but each line is
+  // consumed completely by its lane's loads (L1 hits after the first), and without a staged tile only the
+  // Gear table lives in LDS, so the CU can hold its full 32 waves.
+  const uint64_t gs0 = t0 + (uint64_t)t * L2_STRIP;
+  uint4 wm[4], r[L2_STRIP / 16];
+  auto ld = [&](uint64_t g) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g + 16 <= n) v = load_u4_unaligned(data + g);
+    else if (g < n) { uint8_t tmp[16]; for (int bb = 0; bb < 16; bb++) tmp[bb] = (g + bb < n) ? data[g + bb] : (uint8_t)0; __builtin_memcpy(&v, tmp, 16); }
+    return v;
+  };
+#pragma unroll
+  for (int j = 0; j < 4; j++) wm[j] = gs0 >= 64 ? ld(gs0 - 64 + 16 * j) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < L2_STRIP / 16; j++) r[j] = ld(gs0 + 16 * j);
+  __syncthreads();  // table in place
+  const uint32_t copy = t & (L2_COPIES - 1);
+  uint64_t h = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t w[4] = {wm[j].x, wm[j].y, wm[j].z, wm[j].w};
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) h = (h << 1) + gear_lookup<L2_COPIES>(s_gear, (w[d] >> (8 * b)) & 0xFF, copy);
+  }
+#else
   // stage the tile: 16 B per lane, coalesced, into the padded layout
 #pragma unroll
   for (int k = 0; k < L2_TILE / 16 / L2_NT; k++) {
@@ -103,27 +149,49 @@ __global__ __launch_bounds__(L2_NT) void l2_hash_kernel(const uint8_t* __restric
         for (int b = 0; b < 4; b++) h = (h << 1) + gear_lookup<L2_COPIES>(s_gear, (w[d] >> (8 * b)) & 0xFF, copy);
     }
   }
+#endif
   uint32_t Lm[L2_WORDS], Sm[L2_WORDS];
+#ifndef HMSE_L2_DIRECT
   const uint8_t* mine = s_data + (t + 1) * L2_PSTRIDE;
+#endif
 #pragma unroll
   for (int g = 0; g < L2_WORDS; g++) {
     uint32_t lm = 0, sm = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
+#ifdef HMSE_L2_DIRECT
+      const uint4 v = r[g * 2 + half];
+#else
       const uint4 v = *(const uint4*)(mine + g * 32 + half * 16);
+#endif
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      // hit <=> (hi & mask) == 0 <=> hi < 2^(32-bits) (the masks are top bits): one v_min per byte into a
+      // running minimum; the rare (1/2048) hits are located by replaying the 16 bytes from the saved state
+      const uint64_t h0 = h;
+      uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
       for (int d = 0; d < 4; d++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           h = (h << 1) + gear_lookup<L2_COPIES>(s_gear, (w[d] >> (8 * b)) & 0xFF, copy);
-          const uint32_t hi = (uint32_t)(h >> 32);
-          if ((hi & ml_hi) == 0) {
-            const uint32_t bit = 1u << (half * 16 + d * 4 + b);
-            lm |= bit;
-            if ((hi & ms_hi) == 0) sm |= bit;
-          }
+          mn = min(mn, (uint32_t)(h >> 32));
         }
+      asm volatile("" : "+v"(mn));  // keep this a single compare per 16 bytes
+      if (__builtin_expect(mn < thr_l, 0)) {
+        uint64_t hr = h0;
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            hr = (hr << 1) + gear_lookup<L2_COPIES>(s_gear, (w[d] >> (8 * b)) & 0xFF, copy);
+            const uint32_t hi = (uint32_t)(hr >> 32);
+            if (hi < thr_l) {
+              const uint32_t bit = 1u << (half * 16 + d * 4 + b);
+              lm |= bit;
+              if (hi < thr_s) sm |= bit;
+            }
+          }
+      }
     }
     Lm[g] = lm; Sm[g] = sm;
   }
@@ -386,7 +454,7 @@ extern "C" int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_
   if (n_tiles > 0x7FFFFFFFull) return HMSE_EINVAL;
   if (n_tiles) {
     PROF_BEGIN(HMSE_STAGE_L2_CDC, stream);
-  l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, n, ml_hi, ms_hi, w.cand, w.cand_cap, w.tinfo, w.hdr);
+  l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, n, ~ml_hi + 1u, ms_hi == 0xFFFFFFFFu ? 1u : ~ms_hi + 1u, w.cand, w.cand_cap, w.tinfo, w.hdr);
   PROF_END(HMSE_STAGE_L2_CDC, stream);
     HMSE_LAUNCH_CHECK();
   }
