@@ -117,7 +117,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # HMSE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, reductions) even at world size 1
+    distributed = world > 1 or os.environ.get("HMSE_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
