@@ -25,10 +25,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
-               8: "l1_deflate_kernel<512,9216,9216,true,false>", 9: "l1_deflate_kernel<1024,20480,20480,true,false>",
-               10: "l1_deflate_kernel<1024,26624,13312,true,false>", 11: "l1_deflate_kernel<512,65536,32768,false,false>",
-               12: "l1_deflate_kernel<512,12288,12288,true,true>"}
-DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12}  # size classes S, MF, MD, B, S2 (hmse_amd/csrc/l1_deflate.hip)
+               8: "l1_deflate_kernel<1024,9216,9216,true,false,false>", 9: "l1_deflate_kernel<1024,20480,20480,true,false,false>",
+               10: "l1_deflate_kernel<1024,26624,13312,true,false,false>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false>",
+               12: "l1_deflate_kernel<1024,12288,12288,true,true,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true>"}
+DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12, 5: 13}  # size classes S, MF, MD, B, S2, SG (hmse_amd/csrc/l1_deflate.hip)
 
 
 def parse():
@@ -194,8 +194,8 @@ def main():
         dl = torch.clamp(ul[res.base.clamp(min=0)], max=32768) if res.base is not None else torch.zeros_like(ul)
         jobs_T = torch.cat([ul, (ul + dl)[hb]])
         jobs_L = torch.cat([ul, ul[hb]])
-        cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 20480, 1,
-                          torch.where((jobs_T <= 26624) & (jobs_L <= 13312), 2, 3))))
+        cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 16000, 5, torch.where(jobs_T <= 20480, 1,
+                          torch.where((jobs_T <= 26624) & (jobs_L <= 13312), 2, 3)))))
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
         for c, slot in DEFLATE_CLASS_SLOT.items():
             m = cls == c

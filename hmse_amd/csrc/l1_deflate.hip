@@ -88,7 +88,7 @@ constexpr int align16(int v) { return (v + 15) & ~15; }
 
 // LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
 // !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
-template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false>
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
 struct Layout {
   static constexpr int LCAP = LCAP_;
   static constexpr int W_OFF = 0;
@@ -104,7 +104,7 @@ struct Layout {
   static constexpr int MD_OFF = A_OFF + A_SZ;           // LDSM: u16 mdist[L]
   static constexpr int MD_SZ = (LDSM && !MDG) ? align16(2 * LCAP) : 0;
   static constexpr int ML_OFF = MD_OFF + MD_SZ;         // LDSM: u8 mlen[L]
-  static constexpr int ML_SZ = LDSM ? align16(LCAP) : 0;
+  static constexpr int ML_SZ = (LDSM && !MLG) ? align16(LCAP) : 0;
   static constexpr int K_OFF = ML_OFF + ML_SZ;          // LDSM: u8 K[T] = byte 4 of the position at each sorted rank
   static constexpr int K_SZ = LDSM ? align16(TCAP + 16) : 0;
   static constexpr int TOTAL = K_OFF + K_SZ;
@@ -332,9 +332,9 @@ struct Scratch {
   uint16_t mdist[32768]; uint8_t mlen[32768];
 };
 
-template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false>
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
 __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
-  using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG>;
+  using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
@@ -351,7 +351,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
   uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
   uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
   uint16_t* const mdist = MDG ? mdist_g : LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
-  uint8_t* const mlen = LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
+  // class SG also keeps the match lengths there (LDS then holds only the window, the sorted ranks and the
+  // byte-4 filter: a 16 KB window fits twice per CU)
+  uint8_t* const mlen = MLG ? (uint8_t*)(mdist_g + TCAP) : LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
   uint8_t* const K = LDSM ? (uint8_t*)(smem + LY::K_OFF) : sc->K;
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
@@ -788,15 +790,17 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
 //   S : T <= 9216                 (79 KiB  -> two workgroups of 1024 threads per CU = the CU's full 32 waves;
 //                                  capped at 64 VGPRs: measured 8 % faster than 512 threads at 128 VGPRs, spills included)
 //   S2: T <= 12288                (76 KiB  -> two per CU; match distances in a small global array)
+//   SG: T <= 16000                (79 KiB  -> two per CU; match lengths and distances in the global array)
 //   MF: T <= 20480                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
 //   MD: T <= 26624 and L <= 13312 (161 KiB -> one per CU; chunk + full dictionary)
 // and larger windows (up to 32 KiB + 32 KiB) keep them in a per-workgroup global scratch (B).
-constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288;
+constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000;
 constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_CLASS = 5;
+constexpr int N_CLASS = 6;
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
+static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
 
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
     }
   }
   auto cls = [&](uint64_t T) -> uint32_t {
-    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_MF ? 1u
+    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_MF ? 1u
            : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
   };
   append(in, cls(L), (uint32_t)(k << 1));
@@ -950,7 +954,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per CU, global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..4] job counts per class, [8..12] job cursors
+  uint32_t* counters;  // [0..5] job counts per class, [8..13] job cursors
   uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
   uint8_t* scratch; uint8_t* scratch2; uint8_t* slots; size_t fixed_bytes;
@@ -968,22 +972,22 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.list_stride = 2 * n_sel;
   r.lists = w.take<uint32_t>(N_CLASS * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
-  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(2 * TCAP_S2, 256));
+  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(3 * TCAP_SG, 256));
   r.fixed_bytes = w.off;
   r.slots = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
 }
 
-template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false>
+template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
-  using LY = Layout<NT, TCAP, LCAP, LDSM, MDG>;
+  using LY = Layout<NT, TCAP, LCAP, LDSM, MDG, MLG>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
       return HMSE_EHIP;
     attr_set = true;
   }
-  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -1046,8 +1050,12 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   PROF_BEGIN(8 + 1, stream);
   if (launch_class<NT_M, TCAP_MF, TCAP_MF, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 1, stream);
+  a.scratch = w.scratch2; a.scratch_stride = hmse_align_up(3 * TCAP_SG, 256);
+  sel(5);
+  PROF_BEGIN(8 + 5, stream);
+  if (launch_class<NT_S, TCAP_SG, TCAP_SG, true, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
+  PROF_END(8 + 5, stream);
   sel(4);
-  a.scratch = w.scratch2; a.scratch_stride = hmse_align_up(2 * TCAP_S2, 256);
   PROF_BEGIN(8 + 4, stream);
   if (launch_class<NT_S, TCAP_S2, TCAP_S2, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 4, stream);
