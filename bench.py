@@ -27,7 +27,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
                8: "l1_deflate_kernel<1024,9216,9216,true,false,false>", 9: "l1_deflate_kernel<1024,20480,20480,true,false,false>",
                10: "l1_deflate_kernel<1024,26624,13312,true,false,false>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false>",
-               12: "l1_deflate_kernel<1024,12288,12288,true,true,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true>"}
+               12: "l1_deflate_kernel<1024,12288,12288,true,true,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true>",
+               14: "l1_encode_kernel<256,0,12288>", 15: "l1_encode_kernel<256,12288,32768>"}
 DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12, 5: 13}  # size classes S, MF, MD, B, S2, SG (hmse_amd/csrc/l1_deflate.hip)
 
 
@@ -199,7 +200,12 @@ def main():
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
         for c, slot in DEFLATE_CLASS_SLOT.items():
             m = cls == c
-            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + jobs_L[m].sum().item() / cf_l1)
+            # match kernel: window read + job record written (marks, match lengths and distances: 3.125 B/position)
+            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + 3.125 * jobs_L[m].sum().item())
+        for slot, lo, hi in ((14, 0, 12288), (15, 12288, 32768)):
+            m = (jobs_L > lo) & (jobs_L <= hi)
+            # encode kernel: record + literals read, stream written
+            alg[STAGE_NAMES[slot]] = int((4.125 + 1.0 / cf_l1) * jobs_L[m].sum().item())
     stage_roof = {}
     for name, k in kern.items():
         if name not in alg:

@@ -311,25 +311,33 @@ __device__ unsigned long long g_dfl_stamps[3][16];
 #define STAMP(i) do { } while (0)
 #endif
 
+// Per-job record in the workspace (written by the match kernel, read by the encode kernel):
+//   [lf u32[288]][df u32[32]][ntok u32 ...] | tsym u16[L] | tdist u16[L] | stream slot (L+5, the output)
+// Tokens in parse order: tsym < 256 = literal byte, tsym >= 256 = match of length tsym-253 at distance tdist.
+__host__ __device__ __forceinline__ uint32_t rec_ntok_off() { return 1280u; }
+__host__ __device__ __forceinline__ uint32_t rec_tsym_off() { return 1296u; }
+__host__ __device__ __forceinline__ uint32_t rec_tdist_off(uint32_t L) { return 1296u + ((2u * L + 15u) & ~15u); }
+__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return rec_tdist_off(L) + ((2u * L + 15u) & ~15u); }
+__host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L) { return (rec_slot_off(L) + L + 5u + 255u) & ~255u; }
+
 struct Args {
   const uint8_t* data; uint64_t n;
   const uint64_t* cuts; const uint64_t* chunk_ids; const int64_t* base; uint64_t n_sel;
   uint32_t depth;
-  const uint64_t* slot_off;  // [n_sel] byte offset of chunk k's slot pair
-  uint8_t* slots;            // FULL stream at slot_off[k], DELTA stream at slot_off[k] + slot_stride(len)
-  uint64_t slot_cap; uint32_t* status;
+  const uint64_t* rec_off;   // [n_sel] byte offset of chunk k's record pair (FULL, then DELTA at + rec_size(L))
+  uint8_t* recs;
+  uint64_t rec_cap; uint32_t* status;
   uint32_t* len_full; uint32_t* len_delta;
   uint8_t* scratch; size_t scratch_stride;   // !LDSM only
+  uint8_t* scratch2; size_t scratch2_stride; // match lengths/distances of the classes that keep them out of LDS
   const uint32_t* jobs; const uint32_t* n_jobs; uint32_t* counter;  // this class's job list
 };
 
-__device__ __forceinline__ uint32_t slot_stride(uint32_t len) { return (len + 5 + 15) & ~15u; }
 
 // per-workgroup global scratch of the big class
 struct Scratch {
   uint16_t S[65536]; uint8_t K[65536 + 16];
-  uint16_t jumpA[32768 + 8]; uint16_t jumpB[32768 + 8];
-  uint16_t mdist[32768]; uint8_t mlen[32768];
+  uint16_t jumpA[32768 + 8];
 };
 
 template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
@@ -343,17 +351,10 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
   HuffD* const hsD = (HuffD*)(smem + LY::CUR_OFF + sizeof(HuffL));
   uint32_t* const mark = (uint32_t*)(smem + LY::MARK_OFF);
   Small<NT>& sm = *(Small<NT>*)(smem + LY::SMALL_OFF);
-  uint32_t* const out = (uint32_t*)(smem + LY::A_OFF);
   Scratch* const sc = LDSM ? nullptr : (Scratch*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
-  // class S2 keeps only the match distances in a small per-workgroup global array (written once per match,
-  // read once per emitted match), which lets a 12 KiB window fit twice per CU
-  uint16_t* const mdist_g = MDG ? (uint16_t*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride) : nullptr;
+  uint16_t* const mdist_g = (uint16_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride);  // used by S2/SG/B only
   uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
   uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
-  uint16_t* const mdist = MDG ? mdist_g : LDSM ? (uint16_t*)(smem + LY::MD_OFF) : sc->mdist;
-  // class SG also keeps the match lengths there (LDS then holds only the window, the sorted ranks and the
-  // byte-4 filter: a 16 KB window fits twice per CU)
-  uint8_t* const mlen = MLG ? (uint8_t*)(mdist_g + TCAP) : LDSM ? (uint8_t*)(smem + LY::ML_OFF) : sc->mlen;
   uint8_t* const K = LDSM ? (uint8_t*)(smem + LY::K_OFF) : sc->K;
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
@@ -383,11 +384,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
       if (dl64 > WMAX) { dstart += dl64 - WMAX; dl64 = WMAX; }
       Dl = (uint32_t)dl64;
     }
-    uint8_t* slot = a.slots + a.slot_off[k] + (variant ? slot_stride(L) : 0u);
     uint32_t* len_out = variant ? a.len_delta : a.len_full;
     const uint32_t T = Dl + L;
-    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.slot_off[k] + (variant + 1ull) * slot_stride(L) > a.slot_cap) {
-      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }
+    // job record: histograms and the token list go to the encode kernel through it.  Classes S2/SG/B keep the match
+    // distances (S2) or lengths and distances (SG, B) in a per-workgroup global array while matching.
+    uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
+    uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
+    uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
+    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.rec_off[k] + (variant + 1ull) * rec_size(L) > a.rec_cap) {
+      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
       continue;
     }
     const uint8_t* csrc = a.data + cstart;
@@ -622,168 +627,235 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
     }
     __syncthreads();
     STAMP(4);
-    // the output image overlays the (now dead) S/jump array
-    for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;
-    // ---- phase 7: symbol histograms -----------------------------------------------------------------
-    for (uint32_t x = t; x < L; x += NT) {
-      if ((mark[x >> 5] >> (x & 31)) & 1u) {
-        if (take(x)) {
-          uint32_t code, eb, ev;
-          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev); atomicAdd(&sm.lf[code], 1u);
-          dist_sym(mdist[x], code, eb, ev); atomicAdd(&sm.df[code], 1u);
-        } else atomicAdd(&sm.lf[W[Dl + x]], 1u);
+    // ---- phase 7: tokens in parse order + symbol histograms ------------------------------------------------
+    // token index of a marked position = number of marked positions before it: workgroup prefix scan over the
+    // popcounts of contiguous mark words, then every thread walks the set bits of its own words
+    {
+      uint16_t* const tsym = (uint16_t*)(rec + rec_tsym_off());
+      uint16_t* const tdist = (uint16_t*)(rec + rec_tdist_off(L));
+      const uint32_t nwords = (L + 31) >> 5;
+      const uint32_t wq = (nwords + NT - 1) / NT;
+      const uint32_t w0 = t * wq, w1 = (w0 + wq) < nwords ? (w0 + wq) : nwords;
+      uint32_t cntm = 0;
+      for (uint32_t w = w0; w < w1; w++) cntm += (uint32_t)__builtin_popcount(mark[w]);
+      uint32_t ntok;
+      uint32_t idx = block_exclusive_scan<NT>(cntm, sm.red, &ntok);
+      for (uint32_t w = w0; w < w1; w++) {
+        uint32_t m = mark[w];
+        while (m) {
+          const uint32_t x = (w << 5) + (uint32_t)__builtin_ctz(m);
+          m &= m - 1;
+          if (take(x)) {
+            const uint32_t l3 = mlen[x], dd = mdist[x];
+            uint32_t code, eb, ev;
+            len_sym(l3 + 3u, code, eb, ev); atomicAdd(&sm.lf[code], 1u);
+            dist_sym(dd, code, eb, ev); atomicAdd(&sm.df[code], 1u);
+            tsym[idx] = (uint16_t)(256u + l3); tdist[idx] = (uint16_t)dd;
+          } else {
+            const uint32_t b = W[Dl + x];
+            atomicAdd(&sm.lf[b], 1u);
+            tsym[idx] = (uint16_t)b; tdist[idx] = 0;
+          }
+          idx++;
+        }
       }
-    }
-    if (t == 0) atomicAdd(&sm.lf[256], 1u);
-    __syncthreads();
-    STAMP(5);
-    // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
-    if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
-    if (wave == 1) huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
-    if (wave == 2) {
-      uint32_t fb = 0, xb = 0;
-      for (uint32_t s = lane; s < 286; s += 64) { fb += sm.lf[s] * fixed_len(s); if (s >= 257) xb += sm.lf[s] * len_extra_bits(s); }
-      if (lane < 30) { fb += sm.df[lane] * 5u; xb += sm.df[lane] * dist_extra_bits(lane); }
-      for (int d = 32; d > 0; d >>= 1) { fb += __shfl_down(fb, d, 64); xb += __shfl_down(xb, d, 64); }
-      if (lane == 0) { sm.fixed_bits = fb + xb + 3; sm.extra_bits = xb; }
-    }
-    __syncthreads();
-    STAMP(6);
-    // ---- phase 9: code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) ---------------------------
-    if (wave == 0) {
-      uint32_t nlit = 286, ndist = 30;
-      {  // trailing zero lengths: highest used symbol via ballots
-        uint32_t hi = 0;
-        for (uint32_t b = 0; b < 320; b += 64) { const uint32_t s = b + lane; const uint64_t m = __ballot(s < 286 && sm.ll[s] != 0); if (m) hi = b + 64 - (uint32_t)__builtin_clzll(m); }
-        nlit = hi < 257 ? 257 : hi;
-        const uint64_t md = __ballot(lane < 30 && sm.dl[lane] != 0);
-        ndist = md ? 64 - (uint32_t)__builtin_clzll(md) : 1u;
-      }
-      uint32_t e1, e2;
-      rle_tree_wave<NT>(sm.ll, nlit, &sm, 0, &e1);
-      rle_tree_wave<NT>(sm.dl, ndist, &sm, e1, &e2);
-      for (uint32_t i = lane; i < e2; i += 64) atomicAdd(&sm.cf[sm.rle_sym[i]], 1u);
-      if (lane == 0) { sm.nlit = nlit; sm.ndist = ndist; sm.nr = e2; }
-      wave_sync();
-      huff_lengths_wave(sm.cf, 19, 7, sm.cl, hsD);
-      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-      const uint64_t mo = __ballot(lane < 19 && sm.cl[order[lane < 19 ? lane : 0]] != 0);
-      uint32_t ncl = mo ? 64 - (uint32_t)__builtin_clzll(mo) : 0u;
-      if (ncl < 4) ncl = 4;
-      uint32_t cb = 0;
-      for (uint32_t i = lane; i < e2; i += 64) cb += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
-      for (int d = 32; d > 0; d >>= 1) cb += __shfl_down(cb, d, 64);
-      if (lane == 0) { sm.ncl = ncl; sm.cl_bits = cb; }
-    }
-    if (wave == 1) {
-      uint32_t db = 0;
-      for (uint32_t s = lane; s < 286; s += 64) db += sm.lf[s] * sm.ll[s];
-      if (lane < 30) db += sm.df[lane] * sm.dl[lane];
-      for (int d = 32; d > 0; d >>= 1) db += __shfl_down(db, d, 64);
-      if (lane == 0) sm.data_bits = db;
-    }
-    __syncthreads();
-    if (t == 0) {
-      const uint32_t dhdr = 3 + 14 + 3 * sm.ncl + sm.cl_bits;
-      const uint32_t dyn = dhdr + sm.extra_bits + sm.data_bits;
-      const uint32_t stored = 8u * (5u + L);
-      uint32_t mode;
-      if (stored <= sm.fixed_bits && stored <= dyn) mode = 0;
-      else if (sm.fixed_bits <= dyn) mode = 1;
-      else mode = 2;
-      sm.mode = mode;
-      sm.hdr_bits = mode == 2 ? dhdr : 3u;
-    }
-    __syncthreads();
-    const uint32_t mode = sm.mode;
-    if (mode == 0) {
-      if (t == 0) {
-        slot[0] = 1; slot[1] = (uint8_t)L; slot[2] = (uint8_t)(L >> 8); slot[3] = (uint8_t)~L; slot[4] = (uint8_t)(~L >> 8);
-        len_out[k] = 5 + L;
-      }
-      for (uint32_t x = t; x < L; x += NT) slot[5 + x] = W[Dl + x];
-      continue;
-    }
-    STAMP(7);
-    // ---- phase 10: code tables ------------------------------------------------------------------------------
-    if (mode == 1) {
-      for (uint32_t s = t; s < 288; s += NT) sm.ll[s] = (uint8_t)fixed_len(s);
-      if (t < 32) sm.dl[t] = 5;
+      if (t == 0) { atomicAdd(&sm.lf[256], 1u); *(uint32_t*)(rec + rec_ntok_off()) = ntok; }
       __syncthreads();
+      STAMP(5);
+      uint32_t* const r_hist = (uint32_t*)rec;
+      for (uint32_t i = t; i < 288; i += NT) r_hist[i] = sm.lf[i];
+      if (t < 32) r_hist[288 + t] = sm.df[t];
     }
-    if (wave == 0) huff_codes_wave(sm.ll, mode == 1 ? 288 : 286, sm.lc, hsL->cnt);
-    if (wave == 1) huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
-    if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
-    __syncthreads();
-    STAMP(8);
-    // ---- phase 11: emit ----------------------------------------------------------------------------------------
-    if (wave == 0) {
-      if (lane == 0) { put_bits(out, 0, 1, 1); put_bits(out, 1, mode, 2); }
-      if (mode == 2) {
-        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        if (lane == 0) { put_bits(out, 3, sm.nlit - 257, 5); put_bits(out, 8, sm.ndist - 1, 5); put_bits(out, 13, sm.ncl - 4, 4); }
-        if (lane < sm.ncl) put_bits(out, 17 + 3 * lane, sm.cl[order[lane]], 3);
-        // code-length tokens: contiguous token blocks per lane, wave prefix scan of their bit counts
-        const uint32_t nr = sm.nr, per = (nr + 63) / 64;
-        const uint32_t i0 = lane * per, i1 = (i0 + per) < nr ? (i0 + per) : nr;
-        uint32_t bits = 0;
-        for (uint32_t i = i0; i < i1; i++) bits += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
-        uint32_t inc = bits;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
-        uint32_t off = 17 + 3 * sm.ncl + inc - bits;
-        for (uint32_t i = i0; i < i1; i++) {
-          const uint32_t s = sm.rle_sym[i], l = sm.cl[s], eb = sm.rle_eb[i];
-          put_bits(out, off, (uint32_t)sm.cc[s] | ((uint32_t)sm.rle_ev[i] << l), l + eb);
-          off += l + eb;
-        }
-      }
-    }
-    // token bits: each thread owns a contiguous block of positions
-    const uint32_t per = (L + NT - 1) / NT;
-    const uint32_t x0 = t * per, x1 = (x0 + per) < L ? (x0 + per) : L;
-    uint32_t mybits = 0;
-    for (uint32_t x = x0; x < x1; x++) {
-      if ((mark[x >> 5] >> (x & 31)) & 1u) {
-        if (take(x)) {
-          uint32_t code, eb, ev, dcode, deb, dev;
-          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev);
-          dist_sym(mdist[x], dcode, deb, dev);
-          mybits += sm.ll[code] + eb + sm.dl[dcode] + deb;
-        } else mybits += sm.ll[W[Dl + x]];
-      }
-    }
-    uint32_t total;
-    uint32_t off = block_exclusive_scan<NT>(mybits, sm.red, &total) + sm.hdr_bits;
-    for (uint32_t x = x0; x < x1; x++) {
-      if ((mark[x >> 5] >> (x & 31)) & 1u) {
-        if (take(x)) {
-          uint32_t code, eb, ev, dcode, deb, dev;
-          len_sym((uint32_t)mlen[x] + 3u, code, eb, ev);
-          dist_sym(mdist[x], dcode, deb, dev);
-          const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
-          put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
-          put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb); off += l2 + deb;
-        } else {
-          const uint32_t b = W[Dl + x];
-          put_bits(out, off, sm.lc[b], sm.ll[b]); off += sm.ll[b];
-        }
-      }
-    }
-    const uint32_t end_bits = sm.hdr_bits + total;
-    if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
-    __syncthreads();
-    const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
-    for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // slot is 16-byte aligned and padded
-      const uint4 v = *(const uint4*)((const uint8_t*)out + i);
-      *(uint4*)(slot + i) = v;
-    }
-    if (t == 0) len_out[k] = nbytes;
     STAMP(9);
   }
 #ifdef HMSE_DFL_STAMPS
   if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[LDSM ? (TCAP <= 9216 ? 0 : 1) : 2][i], stamp_acc[i]);
 #endif
+}
+
+
+// ---- encode kernel: Huffman trees, block type, bit image -----------------------------------------------
+// One small workgroup per job; its LDS image is a few KiB plus the output image, so many jobs share a CU
+// and the serial parts of one (two-queue merge, stitching of the header) hide behind the others.
+template <int NT, int LMIN, int LCAP>
+struct EncLayout {
+  static constexpr int SMALL_OFF = 0;
+  static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT>));
+  static constexpr int HS_OFF = SMALL_OFF + SMALL_SZ;
+  static constexpr int HS_SZ = align16((int)(sizeof(HuffL) + sizeof(HuffD)));
+  static constexpr int OUT_OFF = HS_OFF + HS_SZ;
+  static constexpr int OUT_SZ = align16(LCAP + 80);
+  static constexpr int TOTAL = OUT_OFF + OUT_SZ;
+};
+
+template <int NT, int LMIN, int LCAP>
+__global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
+  using EL = EncLayout<NT, LMIN, LCAP>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Small<NT>& sm = *(Small<NT>*)(smem + EL::SMALL_OFF);
+  HuffL* const hsL = (HuffL*)(smem + EL::HS_OFF);
+  HuffD* const hsD = (HuffD*)(smem + EL::HS_OFF + sizeof(HuffL));
+  uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
+  const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+  const uint64_t job = blockIdx.x;
+  if (job >= 2 * a.n_sel) return;
+  const uint64_t k = job >> 1;
+  const uint32_t variant = (uint32_t)(job & 1u);
+  if (variant && !(a.base && a.base[k] >= 0)) return;
+  const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
+  const uint64_t cstart = a.cuts[c];
+  const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
+  if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) return;  // another instantiation's job
+  uint32_t* len_out = variant ? a.len_delta : a.len_full;
+  if (len_out[k] == 0xFFFFFFFFu) return;                  // the match kernel could not take this job
+  uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
+  const uint32_t* const r_hist = (const uint32_t*)rec;
+  const uint32_t ntok = *(const uint32_t*)(rec + rec_ntok_off());
+  const uint16_t* const tsym = (const uint16_t*)(rec + rec_tsym_off());
+  const uint16_t* const tdist = (const uint16_t*)(rec + rec_tdist_off(L));
+  uint8_t* const slot = rec + rec_slot_off(L);
+  const uint8_t* const lit = a.data + cstart;
+  for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = r_hist[i];
+  if (t < 32) sm.df[t] = r_hist[288 + t];
+  if (t < 20) sm.cf[t] = 0;
+  for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;
+  __syncthreads();
+  // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
+  if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
+  if (wave == 1) huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
+  if (wave == 2) {
+    uint32_t fb = 0, xb = 0;
+    for (uint32_t s = lane; s < 286; s += 64) { fb += sm.lf[s] * fixed_len(s); if (s >= 257) xb += sm.lf[s] * len_extra_bits(s); }
+    if (lane < 30) { fb += sm.df[lane] * 5u; xb += sm.df[lane] * dist_extra_bits(lane); }
+    for (int d = 32; d > 0; d >>= 1) { fb += __shfl_down(fb, d, 64); xb += __shfl_down(xb, d, 64); }
+    if (lane == 0) { sm.fixed_bits = fb + xb + 3; sm.extra_bits = xb; }
+  }
+  __syncthreads();
+  // ---- phase 9: code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) ---------------------------
+  if (wave == 0) {
+    uint32_t nlit = 286, ndist = 30;
+    {  // trailing zero lengths: highest used symbol via ballots
+      uint32_t hi = 0;
+      for (uint32_t b = 0; b < 320; b += 64) { const uint32_t s = b + lane; const uint64_t m = __ballot(s < 286 && sm.ll[s] != 0); if (m) hi = b + 64 - (uint32_t)__builtin_clzll(m); }
+      nlit = hi < 257 ? 257 : hi;
+      const uint64_t md = __ballot(lane < 30 && sm.dl[lane] != 0);
+      ndist = md ? 64 - (uint32_t)__builtin_clzll(md) : 1u;
+    }
+    uint32_t e1, e2;
+    rle_tree_wave<NT>(sm.ll, nlit, &sm, 0, &e1);
+    rle_tree_wave<NT>(sm.dl, ndist, &sm, e1, &e2);
+    for (uint32_t i = lane; i < e2; i += 64) atomicAdd(&sm.cf[sm.rle_sym[i]], 1u);
+    if (lane == 0) { sm.nlit = nlit; sm.ndist = ndist; sm.nr = e2; }
+    wave_sync();
+    huff_lengths_wave(sm.cf, 19, 7, sm.cl, hsD);
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    const uint64_t mo = __ballot(lane < 19 && sm.cl[order[lane < 19 ? lane : 0]] != 0);
+    uint32_t ncl = mo ? 64 - (uint32_t)__builtin_clzll(mo) : 0u;
+    if (ncl < 4) ncl = 4;
+    uint32_t cb = 0;
+    for (uint32_t i = lane; i < e2; i += 64) cb += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
+    for (int d = 32; d > 0; d >>= 1) cb += __shfl_down(cb, d, 64);
+    if (lane == 0) { sm.ncl = ncl; sm.cl_bits = cb; }
+  }
+  if (wave == 1) {
+    uint32_t db = 0;
+    for (uint32_t s = lane; s < 286; s += 64) db += sm.lf[s] * sm.ll[s];
+    if (lane < 30) db += sm.df[lane] * sm.dl[lane];
+    for (int d = 32; d > 0; d >>= 1) db += __shfl_down(db, d, 64);
+    if (lane == 0) sm.data_bits = db;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t dhdr = 3 + 14 + 3 * sm.ncl + sm.cl_bits;
+    const uint32_t dyn = dhdr + sm.extra_bits + sm.data_bits;
+    const uint32_t stored = 8u * (5u + L);
+    uint32_t mode;
+    if (stored <= sm.fixed_bits && stored <= dyn) mode = 0;
+    else if (sm.fixed_bits <= dyn) mode = 1;
+    else mode = 2;
+    sm.mode = mode;
+    sm.hdr_bits = mode == 2 ? dhdr : 3u;
+  }
+  __syncthreads();
+  const uint32_t mode = sm.mode;
+  if (mode == 0) {
+    if (t == 0) {
+      slot[0] = 1; slot[1] = (uint8_t)L; slot[2] = (uint8_t)(L >> 8); slot[3] = (uint8_t)~L; slot[4] = (uint8_t)(~L >> 8);
+      len_out[k] = 5 + L;
+    }
+    for (uint32_t x = t; x < L; x += NT) slot[5 + x] = lit[x];
+    return;
+  }
+  // ---- phase 10: code tables ------------------------------------------------------------------------------
+  if (mode == 1) {
+    for (uint32_t s = t; s < 288; s += NT) sm.ll[s] = (uint8_t)fixed_len(s);
+    if (t < 32) sm.dl[t] = 5;
+    __syncthreads();
+  }
+  if (wave == 0) huff_codes_wave(sm.ll, mode == 1 ? 288 : 286, sm.lc, hsL->cnt);
+  if (wave == 1) huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
+  if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
+  __syncthreads();
+  // ---- phase 11: emit ----------------------------------------------------------------------------------------
+  if (wave == 0) {
+    if (lane == 0) { put_bits(out, 0, 1, 1); put_bits(out, 1, mode, 2); }
+    if (mode == 2) {
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      if (lane == 0) { put_bits(out, 3, sm.nlit - 257, 5); put_bits(out, 8, sm.ndist - 1, 5); put_bits(out, 13, sm.ncl - 4, 4); }
+      if (lane < sm.ncl) put_bits(out, 17 + 3 * lane, sm.cl[order[lane]], 3);
+      // code-length tokens: contiguous token blocks per lane, wave prefix scan of their bit counts
+      const uint32_t nr = sm.nr, per = (nr + 63) / 64;
+      const uint32_t i0 = lane * per, i1 = (i0 + per) < nr ? (i0 + per) : nr;
+      uint32_t bits = 0;
+      for (uint32_t i = i0; i < i1; i++) bits += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
+      uint32_t inc = bits;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
+      uint32_t off = 17 + 3 * sm.ncl + inc - bits;
+      for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t s = sm.rle_sym[i], l = sm.cl[s], eb = sm.rle_eb[i];
+        put_bits(out, off, (uint32_t)sm.cc[s] | ((uint32_t)sm.rle_ev[i] << l), l + eb);
+        off += l + eb;
+      }
+    }
+  }
+  // token bits: each thread owns a contiguous block of tokens
+  const uint32_t per = (ntok + NT - 1) / NT;
+  const uint32_t i0 = t * per, i1 = (i0 + per) < ntok ? (i0 + per) : ntok;
+  uint32_t mybits = 0;
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t ts = tsym[i];
+    if (ts >= 256u) {
+      uint32_t code, eb, ev, dcode, deb, dev;
+      len_sym(ts - 253u, code, eb, ev);
+      dist_sym(tdist[i], dcode, deb, dev);
+      mybits += sm.ll[code] + eb + sm.dl[dcode] + deb;
+    } else mybits += sm.ll[ts];
+  }
+  uint32_t total;
+  uint32_t off = block_exclusive_scan<NT>(mybits, sm.red, &total) + sm.hdr_bits;
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t ts = tsym[i];
+    if (ts >= 256u) {
+      uint32_t code, eb, ev, dcode, deb, dev;
+      len_sym(ts - 253u, code, eb, ev);
+      dist_sym(tdist[i], dcode, deb, dev);
+      const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
+      put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
+      put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb); off += l2 + deb;
+    } else {
+      put_bits(out, off, sm.lc[ts], sm.ll[ts]); off += sm.ll[ts];
+    }
+  }
+  const uint32_t end_bits = sm.hdr_bits + total;
+  if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
+  __syncthreads();
+  const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
+  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // slot is 16-byte aligned and padded
+    const uint4 v = *(const uint4*)((const uint8_t*)out + i);
+    *(uint4*)(slot + i) = v;
+  }
+  if (t == 0) len_out[k] = nbytes;
 }
 
 // Size classes (window T = dictionary + chunk, chunk L).  Every per-position array is in LDS for
@@ -840,16 +912,16 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   append(in && hasb, cls(L + Dl), (uint32_t)((k << 1) | 1u));
 }
 
-// slot sizes: FULL (+ DELTA when a base exists), 16-byte aligned; also clears the lengths
-__global__ __launch_bounds__(256) void slot_size_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
-                                                         const int64_t* __restrict__ base, uint64_t n_sel,
-                                                         uint64_t* __restrict__ sizes) {
+// record sizes: FULL (+ DELTA when a base exists)
+__global__ __launch_bounds__(256) void rec_size_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
+                                                        const int64_t* __restrict__ base, uint64_t n_sel,
+                                                        uint64_t* __restrict__ sizes) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_sel) return;
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
-  const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
-  const uint32_t s = slot_stride(len);
-  sizes[k] = (base && base[k] >= 0) ? 2ull * s : (uint64_t)s;
+  const uint64_t len = cuts[c + 1] - cuts[c];
+  const uint64_t s = len <= 32768 ? rec_size((uint32_t)len) : 0u;
+  sizes[k] = (base && base[k] >= 0) ? 2 * s : s;
 }
 
 // kind decision (README.md:1328, 2175 as resolved by SURVEY.md D7) and final lengths
@@ -876,15 +948,16 @@ __global__ __launch_bounds__(256) void decide_kernel(const uint64_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
-                                                      uint64_t n_sel, const uint64_t* __restrict__ slot_off,
-                                                      const uint8_t* __restrict__ slots, const uint8_t* __restrict__ kind,
+                                                      uint64_t n_sel, const uint64_t* __restrict__ rec_off,
+                                                      const uint8_t* __restrict__ recs, const uint8_t* __restrict__ kind,
                                                       const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
                                                       uint64_t out_cap, uint32_t* status) {
   const uint64_t k = blockIdx.x;
   if (k >= n_sel) return;
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
   const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
-  const uint8_t* src = slots + slot_off[k] + ((kind && kind[k] == HMSE_KIND_DELTA) ? slot_stride(len) : 0u);
+  if (len > 32768u) return;
+  const uint8_t* src = recs + rec_off[k] + ((kind && kind[k] == HMSE_KIND_DELTA) ? rec_size(len) : 0u) + rec_slot_off(len);
   const uint64_t o0 = out_off[k], o1 = out_off[k + 1];
   if (o1 > out_cap) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
   const uint32_t nb = (uint32_t)(o1 - o0);
@@ -955,16 +1028,16 @@ constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per 
 
 struct Ws {
   uint32_t* counters;  // [0..5] job counts per class, [8..13] job cursors
-  uint64_t* slot_off; uint64_t* final_len; uint64_t* bsum; uint64_t* slot_total;
+  uint64_t* rec_off; uint64_t* final_len; uint64_t* bsum; uint64_t* rec_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
-  uint8_t* scratch; uint8_t* scratch2; uint8_t* slots; size_t fixed_bytes;
+  uint8_t* scratch; uint8_t* scratch2; uint8_t* recs; size_t fixed_bytes;
 };
 static Ws carve(void* ws, uint64_t n_sel) {
   WsCarver w(ws, ~(size_t)0);
   Ws r;
   r.counters = w.take<uint32_t>(16);
-  r.slot_total = w.take<uint64_t>(1);
-  r.slot_off = w.take<uint64_t>(n_sel + 1);
+  r.rec_total = w.take<uint64_t>(1);
+  r.rec_off = w.take<uint64_t>(n_sel + 1);
   r.final_len = w.take<uint64_t>(n_sel + 1);
   r.bsum = w.take<uint64_t>((n_sel + SC_NT - 1) / SC_NT + 1);
   r.len_full = w.take<uint32_t>(n_sel);
@@ -972,9 +1045,9 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.list_stride = 2 * n_sel;
   r.lists = w.take<uint32_t>(N_CLASS * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
-  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(3 * TCAP_SG, 256));
+  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(3 * 32768, 256));
   r.fixed_bytes = w.off;
-  r.slots = r.scratch ? (uint8_t*)ws + w.off : nullptr;
+  r.recs = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
 }
 
@@ -1018,22 +1091,25 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   if (n_sel > 0x3FFFFFFFull) return HMSE_EINVAL;
   Ws w = carve(ws, n_sel);
   if (!ws || ws_bytes < w.fixed_bytes) return HMSE_ENOSPC;
-  // slot area = whatever follows the fixed part; a job whose slot does not fit sets status bit 1
-  // (needed: sum over selected chunks of align16(len+5), twice where a base exists)
+  // record area = whatever follows the fixed part; a job whose record does not fit sets status bit 1
+  // (needed: sum over selected chunks of rec_size(len) ~ 5*len + 1.6 KiB, twice where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
   HMSE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(uint32_t), stream));
+  HMSE_HIP(hipMemsetAsync(w.len_full, 0, n_sel * sizeof(uint32_t), stream));
+  HMSE_HIP(hipMemsetAsync(w.len_delta, 0, n_sel * sizeof(uint32_t), stream));
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
-  slot_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.slot_off);
+  rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off);
   HMSE_LAUNCH_CHECK();
-  if (exclusive_scan_u64(w.slot_off, n_sel, w.slot_off, w.bsum, w.slot_total, stream) != HMSE_OK) return HMSE_EHIP;
+  if (exclusive_scan_u64(w.rec_off, n_sel, w.rec_off, w.bsum, w.rec_total, stream) != HMSE_OK) return HMSE_EHIP;
   classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.lists, w.list_stride, w.counters);
   HMSE_LAUNCH_CHECK();
   Args a;
   a.data = data; a.n = n; a.cuts = cuts; a.chunk_ids = chunk_ids; a.base = base; a.n_sel = n_sel;
   a.depth = hmse_deflate_depth(cfg);
-  a.slot_off = w.slot_off; a.slots = w.slots; a.len_full = w.len_full; a.len_delta = w.len_delta;
-  a.slot_cap = avail; a.status = status;
+  a.rec_off = w.rec_off; a.recs = w.recs; a.len_full = w.len_full; a.len_delta = w.len_delta;
+  a.rec_cap = avail; a.status = status;
   a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
+  a.scratch2 = w.scratch2; a.scratch2_stride = hmse_align_up(3 * 32768, 256);
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;
   // big windows first (few, long jobs), then the LDS classes
@@ -1050,7 +1126,6 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   PROF_BEGIN(8 + 1, stream);
   if (launch_class<NT_M, TCAP_MF, TCAP_MF, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 1, stream);
-  a.scratch = w.scratch2; a.scratch_stride = hmse_align_up(3 * TCAP_SG, 256);
   sel(5);
   PROF_BEGIN(8 + 5, stream);
   if (launch_class<NT_S, TCAP_SG, TCAP_SG, true, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
@@ -1063,11 +1138,29 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   PROF_BEGIN(8 + 0, stream);
   if (launch_class<NT_S, TCAP_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 0, stream);
+  // encode kernel: one 256-thread workgroup per job, two instantiations by chunk length (LDS image size)
+  {
+    using E1 = EncLayout<256, 0, 12288>;
+    using E2 = EncLayout<256, 12288, 32768>;
+    static bool enc_attr = false;
+    if (!enc_attr) {
+      HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 0, 12288>, hipFuncAttributeMaxDynamicSharedMemorySize, E1::TOTAL));
+      HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL));
+      enc_attr = true;
+    }
+    PROF_BEGIN(14, stream);
+    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)max_jobs), dim3(256), E1::TOTAL, stream>>>(a);
+    PROF_END(14, stream);
+    PROF_BEGIN(15, stream);
+    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)max_jobs), dim3(256), E2::TOTAL, stream>>>(a);
+    PROF_END(15, stream);
+    HMSE_LAUNCH_CHECK();
+  }
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status);
   HMSE_LAUNCH_CHECK();
   if (exclusive_scan_u64(w.final_len, n_sel, out_off, w.bsum, out_off + n_sel, stream) != HMSE_OK) return HMSE_EHIP;
-  gather_kernel<<<dim3((uint32_t)n_sel), dim3(256), 0, stream>>>(cuts, chunk_ids, n_sel, w.slot_off, w.slots, kind, out_off, out,
+  gather_kernel<<<dim3((uint32_t)n_sel), dim3(256), 0, stream>>>(cuts, chunk_ids, n_sel, w.rec_off, w.recs, kind, out_off, out,
                                                                 out_cap, status);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;

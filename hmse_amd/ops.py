@@ -164,16 +164,17 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     kind = torch.zeros(max(n_sel, 0), dtype=torch.uint8, device=dev)
     if n_sel <= 0:
         return torch.empty(0, dtype=torch.uint8, device=dev), out_off, kind
-    if chunk_ids is None:
-        raw = int((cuts[-1] - cuts[0]).item())
-    else:
-        raw = int((cuts[chunk_ids + 1] - cuts[chunk_ids]).sum().item())
+    lens = (cuts[1:] - cuts[:-1]) if chunk_ids is None else (cuts[chunk_ids + 1] - cuts[chunk_ids])
+    # per-job record of the C-ABI workspace (hmse_amd/csrc/l1_deflate.hip rec_size(): histograms, token list, stream slot)
+    rec = (1296 + 2 * ((2 * lens + 15) & ~15) + lens + 5 + 255) & ~255
+    nvar = 1 if base is None else 1 + (base >= 0).to(torch.int64)
+    raw, need = (int(v) for v in torch.stack([lens.sum(), (rec * nvar).sum()]).tolist())
     cap = raw + 5 * n_sel + 64  # a stored block is the worst case
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     c = cfg.to_c()
     nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
-    ws = _ws(nb + (2 if base is not None else 1) * (raw + 20 * n_sel) + 256, dev)
+    ws = _ws(nb + need + 4096, dev)
     rc = _lib.hip_lib().hmse_l1_deflate(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
                                         _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status), ws.data_ptr(), ws.numel(),
                                         _stream())

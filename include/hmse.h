@@ -166,7 +166,10 @@ int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* cfg, uint32
  *   out       DEVICE u8[out_cap]; chunk k's stream is out[out_off[k] .. out_off[k+1])
  *   out_off   DEVICE u64[n_sel+1]
  *   kind      DEVICE u8[n_sel]: HMSE_KIND_FULL or HMSE_KIND_DELTA
- *   status    DEVICE u32[1]: bit0 = out_cap overflow (out_off still exact)
+ *   status    DEVICE u32[1]: bit0 = out_cap overflow (out_off still exact), bit1 = workspace too small
+ *   ws        hmse_workspace_bytes(HMSE_STAGE_L1_DEFLATE, n_sel, cfg) is the FIXED part; after it the call needs
+ *             one job record per encode (FULL, plus DELTA where base >= 0) of about 5*len + 1.6 KiB bytes
+ *             (exact formula: rec_size() in hmse_amd/csrc/l1_deflate.hip, mirrored by hmse_amd/ops.py)
  */
 int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const uint64_t* chunk_ids, const int64_t* base, uint64_t n_sel,
@@ -178,8 +181,8 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
  * kernel launch with a HIP event pair on the caller's stream.  hmse_profile_read() waits for the
  * recorded events (a host sync — never call it inside a capture), adds their durations to the
  * stage's running total and returns it.  Off by default; not part of the data path.
- * Slots: the HMSE_STAGE_* ids; the five DEFLATE size-class kernels report in slots 8..12
- * (S, MF, MD, B, S2 — see hmse_amd/csrc/l1_deflate.hip).
+ * Slots: the HMSE_STAGE_* ids; the six DEFLATE match-kernel size classes report in slots 8..13
+ * (S, MF, MD, B, S2, SG) and the two encode-kernel instantiations in 14 and 15 (hmse_amd/csrc/l1_deflate.hip).
  */
 void hmse_profile_enable(int on);
 int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset);
