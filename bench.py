@@ -200,12 +200,12 @@ def main():
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
         for c, slot in DEFLATE_CLASS_SLOT.items():
             m = cls == c
-            # match kernel: window read + job record written (marks, match lengths and distances: 3.125 B/position)
-            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + 3.125 * jobs_L[m].sum().item())
+            # match kernel: window read + token list written (4 B per token, ~ one token per 3.5 positions)
+            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + 1.15 * jobs_L[m].sum().item())
         for slot, lo, hi in ((14, 0, 12288), (15, 12288, 32768)):
             m = (jobs_L > lo) & (jobs_L <= hi)
-            # encode kernel: record + literals read, stream written
-            alg[STAGE_NAMES[slot]] = int((4.125 + 1.0 / cf_l1) * jobs_L[m].sum().item())
+            # encode kernel: token list read, stream written
+            alg[STAGE_NAMES[slot]] = int((1.15 + 1.0 / cf_l1) * jobs_L[m].sum().item())
     stage_roof = {}
     for name, k in kern.items():
         if name not in alg:

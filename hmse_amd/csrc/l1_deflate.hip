@@ -697,17 +697,22 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
   HuffD* const hsD = (HuffD*)(smem + EL::HS_OFF + sizeof(HuffL));
   uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
-  const uint64_t job = blockIdx.x;
-  if (job >= 2 * a.n_sel) return;
+  const uint32_t n_jobs = *a.n_jobs;
+  for (;;) {
+  __syncthreads();
+  if (t == 0) sm.job = atomicAdd(a.counter, 1u);
+  __syncthreads();
+  const uint32_t ji = sm.job;
+  if (ji >= n_jobs) break;
+  const uint32_t job = a.jobs[ji];
   const uint64_t k = job >> 1;
-  const uint32_t variant = (uint32_t)(job & 1u);
-  if (variant && !(a.base && a.base[k] >= 0)) return;
+  const uint32_t variant = job & 1u;
   const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
   const uint64_t cstart = a.cuts[c];
   const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
-  if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) return;  // another instantiation's job
+  if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) continue;  // (lists are split by length: cannot happen)
   uint32_t* len_out = variant ? a.len_delta : a.len_full;
-  if (len_out[k] == 0xFFFFFFFFu) return;                  // the match kernel could not take this job
+  if (len_out[k] == 0xFFFFFFFFu) continue;                  // the match kernel could not take this job
   uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
   const uint32_t* const r_hist = (const uint32_t*)rec;
   const uint32_t ntok = *(const uint32_t*)(rec + rec_ntok_off());
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
     *(uint4*)(slot + i) = v;
   }
   if (t == 0) len_out[k] = nbytes;
+  }
 }
 
 // Size classes (window T = dictionary + chunk, chunk L).  Every per-position array is in LDS for
@@ -869,7 +875,8 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000;
 constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_CLASS = 6;
+constexpr int N_CLASS = 6;      // match-kernel size classes
+constexpr int N_LIST = 8;       // + two encode-kernel lists (by chunk length)
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   // wave-aggregated append (one atomic per class per wavefront instead of one per job)
   auto append = [&](bool on, uint32_t cl, uint32_t job) {
 #pragma unroll
-    for (uint32_t c = 0; c < (uint32_t)N_CLASS; c++) {
+    for (uint32_t c = 0; c < (uint32_t)N_LIST; c++) {
       const uint64_t m = __ballot(on && cl == c);
       if (m == 0) continue;
       uint32_t base0 = 0;
@@ -908,8 +915,11 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
     return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_MF ? 1u
            : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
   };
+  const bool enc_ok = in && L <= 32768;
   append(in, cls(L), (uint32_t)(k << 1));
   append(in && hasb, cls(L + Dl), (uint32_t)((k << 1) | 1u));
+  append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1));
+  append(enc_ok && hasb, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | 1u));
 }
 
 // record sizes: FULL (+ DELTA when a base exists)
@@ -1027,7 +1037,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per CU, global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..5] job counts per class, [8..13] job cursors
+  uint32_t* counters;  // [0..7] job counts per list, [8..15] job cursors
   uint64_t* rec_off; uint64_t* final_len; uint64_t* bsum; uint64_t* rec_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
   uint8_t* scratch; uint8_t* scratch2; uint8_t* recs; size_t fixed_bytes;
@@ -1043,7 +1053,7 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.len_full = w.take<uint32_t>(n_sel);
   r.len_delta = w.take<uint32_t>(n_sel);
   r.list_stride = 2 * n_sel;
-  r.lists = w.take<uint32_t>(N_CLASS * r.list_stride);
+  r.lists = w.take<uint32_t>(N_LIST * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
   r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(3 * 32768, 256));
   r.fixed_bytes = w.off;
@@ -1148,11 +1158,13 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
       HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL));
       enc_attr = true;
     }
+    sel(6);
     PROF_BEGIN(14, stream);
-    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)max_jobs), dim3(256), E1::TOTAL, stream>>>(a);
+    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 1536 ? max_jobs : 1536)), dim3(256), E1::TOTAL, stream>>>(a);
     PROF_END(14, stream);
+    sel(7);
     PROF_BEGIN(15, stream);
-    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)max_jobs), dim3(256), E2::TOTAL, stream>>>(a);
+    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 768 ? max_jobs : 768)), dim3(256), E2::TOTAL, stream>>>(a);
     PROF_END(15, stream);
     HMSE_LAUNCH_CHECK();
   }
