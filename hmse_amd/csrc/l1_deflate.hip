@@ -312,12 +312,12 @@ __device__ unsigned long long g_dfl_stamps[3][16];
 #endif
 
 // Per-job record in the workspace (written by the match kernel, read by the encode kernel):
-//   [lf u32[288]][df u32[32]][ntok u32 ...] | tsym u16[L] | tdist u16[L] | stream slot (L+5, the output)
-// Tokens in parse order: tsym < 256 = literal byte, tsym >= 256 = match of length tsym-253 at distance tdist.
+//   [lf u32[288]][df u32[32]][ntok u32 ...] | tok u32[L] | stream slot (L+5, the output)
+// Tokens in parse order, one dword each: low half < 256 = literal byte; low half >= 256 = match of length
+// (low-253) at distance (high half).
 __host__ __device__ __forceinline__ uint32_t rec_ntok_off() { return 1280u; }
-__host__ __device__ __forceinline__ uint32_t rec_tsym_off() { return 1296u; }
-__host__ __device__ __forceinline__ uint32_t rec_tdist_off(uint32_t L) { return 1296u + ((2u * L + 15u) & ~15u); }
-__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return rec_tdist_off(L) + ((2u * L + 15u) & ~15u); }
+__host__ __device__ __forceinline__ uint32_t rec_tok_off() { return 1296u; }
+__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return 1296u + 4u * L; }
 __host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L) { return (rec_slot_off(L) + L + 5u + 255u) & ~255u; }
 
 struct Args {
@@ -631,8 +631,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
     // token index of a marked position = number of marked positions before it: workgroup prefix scan over the
     // popcounts of contiguous mark words, then every thread walks the set bits of its own words
     {
-      uint16_t* const tsym = (uint16_t*)(rec + rec_tsym_off());
-      uint16_t* const tdist = (uint16_t*)(rec + rec_tdist_off(L));
+      uint32_t* const tok = (uint32_t*)(rec + rec_tok_off());
       const uint32_t nwords = (L + 31) >> 5;
       const uint32_t wq = (nwords + NT - 1) / NT;
       const uint32_t w0 = t * wq, w1 = (w0 + wq) < nwords ? (w0 + wq) : nwords;
@@ -650,11 +649,11 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) :
             uint32_t code, eb, ev;
             len_sym(l3 + 3u, code, eb, ev); atomicAdd(&sm.lf[code], 1u);
             dist_sym(dd, code, eb, ev); atomicAdd(&sm.df[code], 1u);
-            tsym[idx] = (uint16_t)(256u + l3); tdist[idx] = (uint16_t)dd;
+            tok[idx] = (256u + l3) | (dd << 16);
           } else {
             const uint32_t b = W[Dl + x];
             atomicAdd(&sm.lf[b], 1u);
-            tsym[idx] = (uint16_t)b; tdist[idx] = 0;
+            tok[idx] = b;
           }
           idx++;
         }
@@ -716,8 +715,7 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
   uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
   const uint32_t* const r_hist = (const uint32_t*)rec;
   const uint32_t ntok = *(const uint32_t*)(rec + rec_ntok_off());
-  const uint16_t* const tsym = (const uint16_t*)(rec + rec_tsym_off());
-  const uint16_t* const tdist = (const uint16_t*)(rec + rec_tdist_off(L));
+  const uint32_t* const tok = (const uint32_t*)(rec + rec_tok_off());
   uint8_t* const slot = rec + rec_slot_off(L);
   const uint8_t* const lit = a.data + cstart;
   for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = r_hist[i];
@@ -824,32 +822,53 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
       }
     }
   }
-  // token bits: each thread owns a contiguous block of tokens
-  const uint32_t per = (ntok + NT - 1) / NT;
-  const uint32_t i0 = t * per, i1 = (i0 + per) < ntok ? (i0 + per) : ntok;
+  // token bits: every wavefront owns a contiguous token range and walks it 64 tokens at a time (coalesced
+  // dword loads); bit offsets come from a wave prefix scan per step plus the wave's start offset
+  constexpr uint32_t NWV = NT / 64;
+  const uint32_t wq = ((ntok + NWV - 1) / NWV + 63u) & ~63u;  // tokens per wave, multiple of 64
+  const uint32_t tw0 = wave * wq, tw1 = (tw0 + wq) < ntok ? (tw0 + wq) : ntok;
+  auto tokbits = [&](uint32_t tk) -> uint32_t {
+    const uint32_t ts = tk & 0xFFFFu;
+    if (ts >= 256u) {
+      uint32_t code, eb, ev, dcode, deb, dev;
+      len_sym(ts - 253u, code, eb, ev);
+      dist_sym(tk >> 16, dcode, deb, dev);
+      return sm.ll[code] + eb + sm.dl[dcode] + deb;
+    }
+    return sm.ll[ts];
+  };
   uint32_t mybits = 0;
-  for (uint32_t i = i0; i < i1; i++) {
-    const uint32_t ts = tsym[i];
-    if (ts >= 256u) {
-      uint32_t code, eb, ev, dcode, deb, dev;
-      len_sym(ts - 253u, code, eb, ev);
-      dist_sym(tdist[i], dcode, deb, dev);
-      mybits += sm.ll[code] + eb + sm.dl[dcode] + deb;
-    } else mybits += sm.ll[ts];
-  }
-  uint32_t total;
-  uint32_t off = block_exclusive_scan<NT>(mybits, sm.red, &total) + sm.hdr_bits;
-  for (uint32_t i = i0; i < i1; i++) {
-    const uint32_t ts = tsym[i];
-    if (ts >= 256u) {
-      uint32_t code, eb, ev, dcode, deb, dev;
-      len_sym(ts - 253u, code, eb, ev);
-      dist_sym(tdist[i], dcode, deb, dev);
-      const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
-      put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
-      put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb); off += l2 + deb;
-    } else {
-      put_bits(out, off, sm.lc[ts], sm.ll[ts]); off += sm.ll[ts];
+  for (uint32_t i = tw0 + lane; i < tw1; i += 64) mybits += tokbits(tok[i]);
+  for (int d = 32; d > 0; d >>= 1) mybits += __shfl_down(mybits, d, 64);
+  if (lane == 0) sm.red[wave] = mybits;
+  __syncthreads();
+  uint32_t total = 0, wstart = sm.hdr_bits;
+#pragma unroll
+  for (uint32_t w = 0; w < NWV; w++) { const uint32_t c = sm.red[w]; total += c; if (w < wave) wstart += c; }
+  {
+    uint32_t running = wstart;
+    for (uint32_t i0 = tw0; i0 < tw1; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const uint32_t tk = i < tw1 ? tok[i] : 0u;
+      const uint32_t b = i < tw1 ? tokbits(tk) : 0u;
+      uint32_t inc = b;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
+      uint32_t off = running + inc - b;
+      running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      if (i < tw1) {
+        const uint32_t ts = tk & 0xFFFFu;
+        if (ts >= 256u) {
+          uint32_t code, eb, ev, dcode, deb, dev;
+          len_sym(ts - 253u, code, eb, ev);
+          dist_sym(tk >> 16, dcode, deb, dev);
+          const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
+          put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
+          put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb);
+        } else {
+          put_bits(out, off, sm.lc[ts], sm.ll[ts]);
+        }
+      }
     }
   }
   const uint32_t end_bits = sm.hdr_bits + total;

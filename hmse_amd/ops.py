@@ -166,7 +166,7 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
         return torch.empty(0, dtype=torch.uint8, device=dev), out_off, kind
     lens = (cuts[1:] - cuts[:-1]) if chunk_ids is None else (cuts[chunk_ids + 1] - cuts[chunk_ids])
     # per-job record of the C-ABI workspace (hmse_amd/csrc/l1_deflate.hip rec_size(): histograms, token list, stream slot)
-    rec = (1296 + 2 * ((2 * lens + 15) & ~15) + lens + 5 + 255) & ~255
+    rec = (1296 + 4 * lens + lens + 5 + 255) & ~255
     nvar = 1 if base is None else 1 + (base >= 0).to(torch.int64)
     raw, need = (int(v) for v in torch.stack([lens.sum(), (rec * nvar).sum()]).tolist())
     cap = raw + 5 * n_sel + 64  # a stored block is the worst case
