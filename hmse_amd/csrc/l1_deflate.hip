@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
       len_out[k] = 5 + L;
     }
     for (uint32_t x = t; x < L; x += NT) slot[5 + x] = lit[x];
-    return;
+    continue;  // next job (this workgroup is persistent)
   }
   // ---- phase 10: code tables ------------------------------------------------------------------------------
   if (mode == 1) {
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void decide_kernel(const uint64_t* __restrict_
   if (k >= n_sel) return;
   const uint32_t n1 = len_full[k];
   uint32_t n = n1; uint8_t kd = HMSE_KIND_FULL;
-  if (n1 == 0xFFFFFFFFu) { atomicOr(status, 4u); n = 0; }
+  if (n1 == 0xFFFFFFFFu || n1 == 0u) { atomicOr(status, n1 ? 4u : 8u); n = 0; }  // not encodable / never encoded
   else if (base && base[k] >= 0) {
     const uint32_t n2 = len_delta[k];
     const uint64_t c = chunk_ids ? chunk_ids[k] : k;

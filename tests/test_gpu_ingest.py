@@ -158,3 +158,22 @@ def test_properties_at_scale_256MiB(dev):
         assert d.eof
     st = ingest.merge_stats([a.stats])
     assert st["cf"] > 2.0 and 0 < st["delta_rate"] < 1
+
+
+def test_incompressible_input_at_scale(dev):
+    """PRNG bytes, seed 0xDEADBEEF (VALIDATION_METHODS.md:213): CF ~ 1, every chunk a stored block.  More jobs than
+    the persistent encode grid has workgroups, so a workgroup must survive the stored-block path."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest, ops
+    cfg = IngestConfig()
+    host = corpus.random_bytes(96 << 20)
+    data = torch.from_numpy(host).to(dev)
+    res = ingest.ingest_shard(data, cfg)
+    L = (res.cuts[1:] - res.cuts[:-1])[res.uniq_ids]
+    ln = res.stream_off[1:] - res.stream_off[:-1]
+    assert torch.equal(ln, L + 5) and int((res.kind != 0).sum()) == 0
+    off = res.stream_off.cpu().numpy(); out = res.streams.cpu().numpy(); cuts = res.cuts.cpu().numpy()
+    for k in (0, 1, len(off) // 2, len(off) - 2):
+        assert zlib.decompress(out[off[k]:off[k + 1]].tobytes(), -15) == host[cuts[k]:cuts[k + 1]].tobytes()
+    st = ingest.merge_stats([res.stats])
+    assert 0.98 < st["cf"] < 1.0
