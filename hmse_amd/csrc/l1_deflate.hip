@@ -341,7 +341,7 @@ struct Scratch {
 };
 
 template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
-__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 12288 ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
+__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 16000 ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
   using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -688,7 +688,7 @@ struct EncLayout {
 };
 
 template <int NT, int LMIN, int LCAP>
-__global__ __launch_bounds__(NT) void l1_encode_kernel(Args a) {
+__global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
   using EL = EncLayout<NT, LMIN, LCAP>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Small<NT>& sm = *(Small<NT>*)(smem + EL::SMALL_OFF);
