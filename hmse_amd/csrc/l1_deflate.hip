@@ -88,7 +88,7 @@ constexpr int align16(int v) { return (v + 15) & ~15; }
 
 // LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
 // !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
-template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
 struct Layout {
   static constexpr int LCAP = LCAP_;
   static constexpr int W_OFF = 0;
@@ -106,7 +106,7 @@ struct Layout {
   static constexpr int ML_OFF = MD_OFF + MD_SZ;         // LDSM: u8 mlen[L]
   static constexpr int ML_SZ = (LDSM && !MLG) ? align16(LCAP) : 0;
   static constexpr int K_OFF = ML_OFF + ML_SZ;          // LDSM: u8 K[T] = byte 4 of the position at each sorted rank
-  static constexpr int K_SZ = LDSM ? align16(TCAP + 16) : 0;
+  static constexpr int K_SZ = (LDSM && !NOK) ? align16(TCAP + 16) : 0;
   static constexpr int TOTAL = K_OFF + K_SZ;
   static_assert(TOTAL <= 160 * 1024, "one workgroup's LDS image must fit the CU's 160 KiB");
   static_assert(sizeof(HuffL) + sizeof(HuffD) <= CUR_SZ, "Huffman scratch must fit the cursor table");
@@ -340,9 +340,9 @@ struct Scratch {
   uint16_t jumpA[32768 + 8];
 };
 
-template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false>
-__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 16000 ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
-  using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG>;
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
+__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
+  using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG, NOK>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 16000 ? 8 : 4) :
           for (uint32_t jj = before; jj < after; jj++) r += S[jj] < q;
         }
         __syncthreads();
-        if (act) { S[before + r] = (uint16_t)q; K[before + r] = W[q + 4]; }
+        if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = W[q + 4]; }
       }
       __syncthreads();  // cursor h now = end of bucket h
     }
@@ -495,7 +495,8 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 16000 ? 8 : 4) :
               const uint32_t pp = S[ii];
               if (pp >= Dl) {  // dictionary positions are candidates only: the lane pulls again next round
                 i = ii; p = pp;
-                qn = i ? S[i - 1] : 0u; kn = i ? K[i - 1] : 0u;  // first candidate (used iff kmax != 0)
+                qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
+                kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
                 pw0 = ld32(W + p); pw1 = ld32(W + p + 4);
                 const uint32_t h = hash4(pw0);
                 const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 16000 ? 8 : 4) :
         if (st == PROBE) {
           q = qn;
           const uint32_t kb = kn;
-          if (kk < kmax) { qn = S[i - kk - 1]; kn = K[i - kk - 1]; }  // prefetch the next candidate (sequential, conflict-free)
+          if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }  // prefetch the next candidate
           fin = true; ml = 0;
           if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
           else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
@@ -888,17 +889,20 @@ __global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
 //                                  capped at 64 VGPRs: measured 8 % faster than 512 threads at 128 VGPRs, spills included)
 //   S2: T <= 12288                (76 KiB  -> two per CU; match distances in a small global array)
 //   SG: T <= 16000                (79 KiB  -> two per CU; match lengths and distances in the global array)
-//   MF: T <= 20480                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
+//   SG2: T <= 21504               (80 KiB  -> two per CU; as SG and without the byte-4 filter array)
+//   MF: T <= 20480 (only reached when SG2's record scratch is unavailable; kept for reference)
+//   --                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
 //   MD: T <= 26624 and L <= 13312 (161 KiB -> one per CU; chunk + full dictionary)
 // and larger windows (up to 32 KiB + 32 KiB) keep them in a per-workgroup global scratch (B).
-constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000;
+constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
 constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_CLASS = 6;      // match-kernel size classes
-constexpr int N_LIST = 8;       // + two encode-kernel lists (by chunk length)
+constexpr int N_CLASS = 7;      // match-kernel size classes
+constexpr int N_LIST = 9;       // + two encode-kernel lists (by chunk length): lists 6 and 7; class SG2 is list 8
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
+static_assert(2 * Layout<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>::TOTAL <= 160 * 1024, "class SG2 must fit twice per CU");
 
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
     }
   }
   auto cls = [&](uint64_t T) -> uint32_t {
-    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_MF ? 1u
+    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_SG2 ? 8u
            : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
   };
   const bool enc_ok = in && L <= 32768;
@@ -1056,7 +1060,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per CU, global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..7] job counts per list, [8..15] job cursors
+  uint32_t* counters;  // [0..8] job counts per list, [16..24] job cursors
   uint64_t* rec_off; uint64_t* final_len; uint64_t* bsum; uint64_t* rec_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
   uint8_t* scratch; uint8_t* scratch2; uint8_t* recs; size_t fixed_bytes;
@@ -1064,7 +1068,7 @@ struct Ws {
 static Ws carve(void* ws, uint64_t n_sel) {
   WsCarver w(ws, ~(size_t)0);
   Ws r;
-  r.counters = w.take<uint32_t>(16);
+  r.counters = w.take<uint32_t>(32);
   r.rec_total = w.take<uint64_t>(1);
   r.rec_off = w.take<uint64_t>(n_sel + 1);
   r.final_len = w.take<uint64_t>(n_sel + 1);
@@ -1080,16 +1084,16 @@ static Ws carve(void* ws, uint64_t n_sel) {
   return r;
 }
 
-template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false>
+template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
-  using LY = Layout<NT, TCAP, LCAP, LDSM, MDG, MLG>;
+  using LY = Layout<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
       return HMSE_EHIP;
     attr_set = true;
   }
-  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -1123,7 +1127,7 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   // record area = whatever follows the fixed part; a job whose record does not fit sets status bit 1
   // (needed: sum over selected chunks of rec_size(len) ~ 5*len + 1.6 KiB, twice where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
-  HMSE_HIP(hipMemsetAsync(w.counters, 0, 16 * sizeof(uint32_t), stream));
+  HMSE_HIP(hipMemsetAsync(w.counters, 0, 32 * sizeof(uint32_t), stream));
   HMSE_HIP(hipMemsetAsync(w.len_full, 0, n_sel * sizeof(uint32_t), stream));
   HMSE_HIP(hipMemsetAsync(w.len_delta, 0, n_sel * sizeof(uint32_t), stream));
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
@@ -1142,7 +1146,7 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;
   // big windows first (few, long jobs), then the LDS classes
-  auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 8 + c; };
+  auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 16 + c; };
   sel(3);
   PROF_BEGIN(8 + 3, stream);
   if (launch_class<NT_B, TCAP_B, LCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
@@ -1151,9 +1155,9 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   PROF_BEGIN(8 + 2, stream);
   if (launch_class<NT_M, TCAP_MD, LCAP_MD, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 2, stream);
-  sel(1);
+  sel(8);
   PROF_BEGIN(8 + 1, stream);
-  if (launch_class<NT_M, TCAP_MF, TCAP_MF, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  if (launch_class<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 1, stream);
   sel(5);
   PROF_BEGIN(8 + 5, stream);
