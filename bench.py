@@ -26,10 +26,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
                8: "l1_deflate_kernel<1024,9216,9216,true,false,false,false>", 9: "l1_deflate_kernel<1024,21504,21504,true,true,true,true>",
-               10: "l1_deflate_kernel<1024,26624,13312,true,false,false,false>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false,false>",
+               10: "l1_deflate_kernel<1024,32768,32768,true,true,true,true>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false,false>",
                12: "l1_deflate_kernel<1024,12288,12288,true,true,false,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true,false>",
                14: "l1_encode_kernel<256,0,12288>", 15: "l1_encode_kernel<256,12288,32768>"}
-# match-kernel size classes S, SG2, MD, B, S2, SG (hmse_amd/csrc/l1_deflate.hip) -> profile slot
+# match-kernel size classes S, SG2, SG3, B, S2, SG (hmse_amd/csrc/l1_deflate.hip) -> profile slot
 DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12, 5: 13}
 
 
@@ -197,7 +197,7 @@ def main():
         jobs_T = torch.cat([ul, (ul + dl)[hb]])
         jobs_L = torch.cat([ul, ul[hb]])
         cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 16000, 5, torch.where(jobs_T <= 21504, 1,
-                          torch.where((jobs_T <= 26624) & (jobs_L <= 13312), 2, 3)))))
+                          torch.where(jobs_T <= 32768, 2, 3)))))
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
         for c, slot in DEFLATE_CLASS_SLOT.items():
             m = cls == c

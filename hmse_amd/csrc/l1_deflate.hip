@@ -884,18 +884,16 @@ __global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
   }
 }
 
-// Size classes (window T = dictionary + chunk, chunk L).  Every per-position array is in LDS for
-//   S : T <= 9216                 (79 KiB  -> two workgroups of 1024 threads per CU = the CU's full 32 waves;
-//                                  capped at 64 VGPRs: measured 8 % faster than 512 threads at 128 VGPRs, spills included)
-//   S2: T <= 12288                (76 KiB  -> two per CU; match distances in a small global array)
-//   SG: T <= 16000                (79 KiB  -> two per CU; match lengths and distances in the global array)
-//   SG2: T <= 21504               (80 KiB  -> two per CU; as SG and without the byte-4 filter array)
-//   MF: T <= 20480 (only reached when SG2's record scratch is unavailable; kept for reference)
-//   --                (159 KiB -> one per CU; long chunks, short-dictionary deltas)
-//   MD: T <= 26624 and L <= 13312 (161 KiB -> one per CU; chunk + full dictionary)
-// and larger windows (up to 32 KiB + 32 KiB) keep them in a per-workgroup global scratch (B).
+// Size classes of the match kernel (window T = dictionary + chunk).  Per-position arrays in LDS:
+//   S  : T <= 9216   window, sorted ranks, byte-4 filter, match lengths and distances   (79 KiB, two per CU)
+//   S2 : T <= 12288  as S, match distances in a per-workgroup global array              (76 KiB, two per CU)
+//   SG : T <= 16000  as S2, match lengths there too                                     (79 KiB, two per CU)
+//   SG2: T <= 21504  as SG, without the byte-4 filter array                             (80 KiB, two per CU)
+//   SG3: T <= 32768  as SG2                                                             (115 KiB, one per CU)
+//   B  : T <= 65536  window in LDS, everything else in a per-workgroup global scratch (dictionary jobs only)
+// Two-per-CU classes run 1024 threads capped at 64 VGPRs: the CU's full 32 waves.
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
-constexpr int NT_M = 1024, TCAP_MF = 20480, TCAP_MD = 26624, LCAP_MD = 13312;
+constexpr int NT_M = 1024, TCAP_SG3 = 32768;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
 constexpr int N_CLASS = 7;      // match-kernel size classes
 constexpr int N_LIST = 9;       // + two encode-kernel lists (by chunk length): lists 6 and 7; class SG2 is list 8
@@ -936,7 +934,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   }
   auto cls = [&](uint64_t T) -> uint32_t {
     return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_SG2 ? 8u
-           : (T <= (uint64_t)TCAP_MD && L <= (uint64_t)LCAP_MD) ? 2u : 3u;
+           : T <= (uint64_t)TCAP_SG3 ? 2u : 3u;
   };
   const bool enc_ok = in && L <= 32768;
   append(in, cls(L), (uint32_t)(k << 1));
@@ -1153,7 +1151,7 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   PROF_END(8 + 3, stream);
   sel(2);
   PROF_BEGIN(8 + 2, stream);
-  if (launch_class<NT_M, TCAP_MD, LCAP_MD, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
+  if (launch_class<NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
   PROF_END(8 + 2, stream);
   sel(8);
   PROF_BEGIN(8 + 1, stream);

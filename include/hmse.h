@@ -182,7 +182,7 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
  * recorded events (a host sync — never call it inside a capture), adds their durations to the
  * stage's running total and returns it.  Off by default; not part of the data path.
  * Slots: the HMSE_STAGE_* ids; the six DEFLATE match-kernel size classes report in slots 8..13
- * (S, SG2, MD, B, S2, SG) and the two encode-kernel instantiations in 14 and 15 (hmse_amd/csrc/l1_deflate.hip).
+ * (S, SG2, SG3, B, S2, SG) and the two encode-kernel instantiations in 14 and 15 (hmse_amd/csrc/l1_deflate.hip).
  */
 void hmse_profile_enable(int on);
 int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset);
