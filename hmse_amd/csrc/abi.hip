@@ -7,6 +7,7 @@ size_t hmse_l3_dedup_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l4_lsh_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
+size_t hmse_l1_inflate_workspace_bytes_impl(uint64_t n_chunks);
 
 extern "C" void hmse_cfg_default(hmse_cfg* c) {
   memset(c, 0, sizeof *c);
@@ -88,6 +89,8 @@ extern "C" size_t hmse_workspace_bytes(int stage, uint64_t n, const hmse_cfg* cf
     case HMSE_STAGE_L4_MINHASH: return hmse_l4_minhash_workspace_bytes_impl(n);
     case HMSE_STAGE_L4_LSH: return hmse_l4_lsh_workspace_bytes_impl(n, cfg);
     case HMSE_STAGE_L1_DEFLATE: return hmse_l1_deflate_workspace_bytes_impl(n, cfg);
+    case HMSE_STAGE_L1_INFLATE: return hmse_l1_inflate_workspace_bytes_impl(n);
+    case HMSE_STAGE_READ_ASSEMBLE: return 256;
     default: return 0;
   }
 }
@@ -97,7 +100,7 @@ int g_hmse_prof = 0;
 namespace {
 constexpr int PROF_RING = 64;
 struct ProfStage { hipEvent_t e0[PROF_RING], e1[PROF_RING]; int n = 0; bool init = false; double ms = 0; uint64_t launches = 0; };
-ProfStage g_ps[16];
+ProfStage g_ps[32];
 void prof_flush(ProfStage& p) {
   for (int i = 0; i < p.n; i++) {
     float t = 0;
@@ -107,19 +110,19 @@ void prof_flush(ProfStage& p) {
 }
 }  // namespace
 void hmse_prof_begin(int stage, hipStream_t s) {
-  ProfStage& p = g_ps[stage & 15];
+  ProfStage& p = g_ps[stage & 31];
   if (!p.init) { for (int i = 0; i < PROF_RING; i++) { (void)hipEventCreate(&p.e0[i]); (void)hipEventCreate(&p.e1[i]); } p.init = true; }
   if (p.n == PROF_RING) prof_flush(p);
   (void)hipEventRecord(p.e0[p.n], s);
 }
 void hmse_prof_end(int stage, hipStream_t s) {
-  ProfStage& p = g_ps[stage & 15];
+  ProfStage& p = g_ps[stage & 31];
   (void)hipEventRecord(p.e1[p.n], s);
   p.n++;
 }
 extern "C" void hmse_profile_enable(int on) { g_hmse_prof = on; }
 extern "C" int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset) {
-  if (stage < 0 || stage > 15) return HMSE_EINVAL;
+  if (stage < 0 || stage > 31) return HMSE_EINVAL;
   ProfStage& p = g_ps[stage];
   prof_flush(p);
   if (total_ms) *total_ms = p.ms;

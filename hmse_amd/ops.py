@@ -15,6 +15,7 @@ from . import _lib
 from .config import IngestConfig
 
 STAGE_L2, STAGE_SHA, STAGE_DEDUP, STAGE_MINHASH, STAGE_LSH, STAGE_DEFLATE = 2, 3, 4, 5, 6, 7
+STAGE_INFLATE, STAGE_ASSEMBLE = 16, 17
 
 
 class HmseError(RuntimeError):
@@ -183,3 +184,59 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     if int(status.item()):
         raise HmseError(-2, f"hmse_l1_deflate device status {int(status.item()):#x}")
     return out[:total], out_off, kind
+
+
+def l1_inflate(streams: torch.Tensor, stream_off: torch.Tensor, kind: torch.Tensor, base: torch.Tensor | None,
+               raw_len: torch.Tensor, stream_len: torch.Tensor | None = None, check: bool = True):
+    """Raw-DEFLATE decode of stored chunks; DELTA chunks use their base chunk's raw bytes as dictionary.
+
+    `stream_off` int64[n+1] (dense) or int64[n] starts with `stream_len` int32[n]; `raw_len` int64[n] raw chunk sizes.
+    Returns (raw uint8[sum(raw_len)], raw_off int64[n+1], ok uint8[n]); with check=True a corrupt record raises.
+    README.md:2397-2400, 1635-1669."""
+    _require_gpu(streams, "streams")
+    _require_gpu(stream_off, "stream_off")
+    _require_gpu(kind, "kind")
+    _require_gpu(raw_len, "raw_len")
+    dev = streams.device
+    n_sel = kind.numel()
+    if stream_off.numel() != (n_sel if stream_len is not None else n_sel + 1) or raw_len.numel() != n_sel:
+        raise HmseError(-1, "l1_inflate: stream_off / raw_len do not match kind")
+    raw_off = torch.zeros(n_sel + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(raw_len, 0, out=raw_off[1:])
+    total = int(raw_off[-1].item()) if n_sel else 0
+    raw = torch.empty(total, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ok = torch.zeros(n_sel, dtype=torch.uint8, device=dev)
+    if n_sel == 0:
+        return raw, raw_off, ok
+    if base is not None:
+        _require_gpu(base, "base")
+    if stream_len is not None:
+        _require_gpu(stream_len, "stream_len")
+    ws = _ws(workspace_bytes(STAGE_INFLATE, n_sel, IngestConfig()), dev)
+    keep = torch.empty(1, dtype=torch.uint8, device=dev) if total == 0 else raw  # a valid pointer even when every chunk is empty
+    rc = _lib.hip_lib().hmse_l1_inflate(_ptr(streams), streams.numel(), _ptr(stream_off), _ptr(stream_len), _ptr(kind), _ptr(base),
+                                        n_sel, _ptr(raw_off), _ptr(keep), total, _ptr(ok), _ptr(status), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_l1_inflate")
+    st = int(status.item())
+    if check and st:
+        raise HmseError(-1, f"hmse_l1_inflate: {int((ok == 0).sum().item())} corrupt record(s), device status {st:#x}")
+    return raw, raw_off, ok
+
+
+def read_assemble(cuts: torch.Tensor, slot_of_chunk: torch.Tensor, raw_off: torch.Tensor, raw: torch.Tensor) -> torch.Tensor:
+    """Lay the stored chunks out as the original data: chunk i <- raw bytes of slot_of_chunk[i]. README.md:1635-1669."""
+    for t, nm in ((cuts, "cuts"), (slot_of_chunk, "slot_of_chunk"), (raw_off, "raw_off"), (raw, "raw")):
+        _require_gpu(t, nm)
+    n_chunks = cuts.numel() - 1
+    n = int(cuts[-1].item()) if n_chunks > 0 else 0
+    out = torch.empty(n, dtype=torch.uint8, device=cuts.device)
+    status = torch.zeros(1, dtype=torch.int32, device=cuts.device)
+    if n_chunks <= 0 or n == 0:
+        return out
+    rc = _lib.hip_lib().hmse_read_assemble(_ptr(cuts), n_chunks, _ptr(slot_of_chunk), raw_off.numel() - 1, _ptr(raw_off), _ptr(raw),
+                                           _ptr(out), n, _ptr(status), _stream())
+    _check(rc, "hmse_read_assemble")
+    if int(status.item()):
+        raise HmseError(-1, "hmse_read_assemble: chunk map disagrees with the stored lengths")
+    return out

@@ -1,0 +1,82 @@
+"""The read path on the GPU: stored records -> original bytes, verified by SHA-256.
+
+Three branches as in the reference (README.md:1621-1675, 2191-2198): FULL -> inflate; DELTA -> inflate with the
+base chunk as dictionary; POINTER -> the target chunk's bytes.  All of it runs in the hand-written kernels of
+hmse_amd/csrc/l1_inflate.hip and the L3 SHA-256 kernel (the reference's "100 % checksum pass" gate, README.md:1329).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import KIND_DELTA, KIND_POINTER
+from .manifest import Manifest
+
+
+class ReadError(RuntimeError):
+    pass
+
+
+def reconstruct_shard(res, verify: bool = True) -> torch.Tensor:
+    """Inverse of ingest_shard for a ShardResult whose first occurrences are all local (one shard)."""
+    cuts = res.cuts
+    n_chunks = cuts.numel() - 1
+    dev = cuts.device
+    lens = cuts[1:] - cuts[:-1]
+    if res.streams is None:
+        raise ReadError("reconstruct_shard needs the L1 layer's streams")
+    raw, raw_off, _ = ops.l1_inflate(res.streams, res.stream_off, res.kind, res.base, lens[res.uniq_ids])
+    slot_of = torch.full((n_chunks,), -1, dtype=torch.int64, device=dev)
+    slot_of[res.uniq_ids] = torch.arange(res.uniq_ids.numel(), dtype=torch.int64, device=dev)
+    if res.first_occ is not None:
+        fo = res.first_occ - res.chunk_base
+        if bool(((fo < 0) | (fo >= n_chunks)).any()):
+            raise ReadError("a first occurrence lives on another shard")
+        slot_of = slot_of[fo]
+    data = ops.read_assemble(cuts, slot_of, raw_off, raw)
+    if verify and res.digests is not None:
+        verify_digests(data, cuts, res.digests)
+    return data
+
+
+def verify_digests(data: torch.Tensor, cuts: torch.Tensor, digests: torch.Tensor) -> None:
+    got = ops.l3_sha256(data, cuts)
+    if not torch.equal(got, digests):
+        bad = int((got != digests).any(dim=1).sum().item())
+        raise ReadError(f"SHA-256 mismatch on {bad} of {digests.shape[0]} reconstructed chunks")
+
+
+def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
+    """Manifest bytes (hmse_amd/manifest.py record formats) -> original data, decoded on `device`."""
+    idx, cmap = m.index, m.chunk_map
+    u, n = len(idx), len(cmap)
+    own = cmap["kind"] != KIND_POINTER
+    slot_kind = np.zeros(u, np.uint8)
+    slot_kind[cmap["slot"][own]] = cmap["kind"][own]
+    raw_len = np.zeros(u, np.int64)
+    raw_len[cmap["slot"]] = cmap["raw_length"]
+    rec_off = idx["lba"].astype(np.int64) * m.lba_unit
+    is_delta = slot_kind == KIND_DELTA
+    s_off = rec_off + np.where(is_delta, 8, 0)
+    s_len = idx["length"].astype(np.int64) - np.where(is_delta, 8, 0)
+    base = np.full(u, -1, np.int64)
+    if is_delta.any():
+        # DeltaChunk header {base_lba u32, base_length u16, delta_length u16} (README.md:2182-2189)
+        hdr_pos = rec_off[is_delta][:, None] + np.arange(8)[None, :]
+        hdr = m.blob[hdr_pos].copy().view("<u4")  # [:,0] base_lba, [:,1] lengths
+        order = np.argsort(idx["lba"], kind="stable")
+        pos = np.searchsorted(idx["lba"][order], hdr[:, 0])
+        if (pos >= u).any() or (idx["lba"][order][np.minimum(pos, u - 1)] != hdr[:, 0]).any():
+            raise ReadError("a DeltaChunk header names an LBA that is not in the index")
+        base[is_delta] = order[pos]
+        s_len[is_delta] = hdr[:, 1] >> 16
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
+    raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(s_off, torch.int64), t(slot_kind, torch.uint8), t(base, torch.int64),
+                                     t(raw_len, torch.int64), stream_len=t(s_len, torch.int32))
+    cuts = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(t(raw_len[cmap["slot"]], torch.int64), 0, out=cuts[1:])
+    data = ops.read_assemble(cuts, t(cmap["slot"].astype(np.int64), torch.int64), raw_off, raw)
+    if verify and u and idx["sha256"].any():
+        verify_digests(data, cuts, t(idx["sha256"][cmap["slot"]], torch.uint8))
+    return data

@@ -42,7 +42,10 @@ enum {
   HMSE_STAGE_L3_DEDUP   = 4,
   HMSE_STAGE_L4_MINHASH = 5,
   HMSE_STAGE_L4_LSH     = 6,
-  HMSE_STAGE_L1_DEFLATE = 7
+  HMSE_STAGE_L1_DEFLATE = 7,
+  /* read path; ids 8..15 are the DEFLATE kernels' profiling slots */
+  HMSE_STAGE_L1_INFLATE    = 16,
+  HMSE_STAGE_READ_ASSEMBLE = 17
 };
 
 /* layer-enable mask == the reference's ablation matrix / degradation modes
@@ -177,11 +180,43 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * Read path, L1 — raw DEFLATE decode of stored chunks.  Replaces mz_inflateInit2(&s, 15) + mz_inflate(&s, MZ_FINISH)
+ * (README.md:2397-2400) and the FULL / DELTA branches of the read path (README.md:1635-1669, 2191-2198): a DELTA
+ * record inflates with the raw bytes of its base chunk as preset dictionary (the last 32 KiB of them).
+ *   streams    DEVICE u8[streams_bytes]
+ *   stream_off DEVICE u64[n_sel+1] (dense: stream k = [off[k], off[k+1]))  or, with stream_len != NULL,
+ *              DEVICE u64[n_sel] starts + stream_len DEVICE u32[n_sel] (records inside a manifest blob)
+ *   kind       DEVICE u8[n_sel]  HMSE_KIND_FULL / HMSE_KIND_DELTA;  base DEVICE i64[n_sel] or NULL: slot of the
+ *              dictionary chunk, must be < k (the writer only ever picks earlier chunks)
+ *   raw_off    DEVICE u64[n_sel+1]: where each chunk's raw bytes go in raw_out (exclusive prefix sum of raw lengths)
+ *   ok         DEVICE u8[n_sel] or NULL: 1 where chunk k decoded, 0 where its record is corrupt
+ *   status     DEVICE u32[1]: bit0 = at least one record is corrupt (the streams stock zlib rejects: bad block type or
+ *              code set, undefined code, distance beyond the window, stored LEN/NLEN mismatch; plus: decoded size !=
+ *              recorded raw length, stream not ending in its last byte, DELTA with a missing/corrupt base) — that
+ *              chunk's bytes are undefined, every other chunk is still decoded
+ *   ws         hmse_workspace_bytes(HMSE_STAGE_L1_INFLATE, n_sel, cfg)
+ */
+int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, const uint64_t* stream_off,
+                    const uint32_t* stream_len, const uint8_t* kind, const int64_t* base, uint64_t n_sel,
+                    const uint64_t* raw_off, uint8_t* raw_out, uint64_t raw_cap, uint8_t* ok,
+                    uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Read path — POINTER branch and final layout (README.md:1635-1669): chunk i of the original data is the raw
+ * bytes of stored slot slot_of_chunk[i] (its own slot for FULL/DELTA, the target's for POINTER).
+ *   cuts DEVICE u64[n_chunks+1]; slot_of_chunk DEVICE u64[n_chunks]; raw_off DEVICE u64[n_slots+1]; raw DEVICE u8[]
+ *   data_out DEVICE u8[n];  status DEVICE u32[1]: bit0 = a map entry disagrees with the stored lengths
+ */
+int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* slot_of_chunk, uint64_t n_slots,
+                       const uint64_t* raw_off, const uint8_t* raw, uint8_t* data_out, uint64_t n,
+                       uint32_t* status, void* stream);
+
+/*
  * Diagnostics (bench.py's roofline leg): when enabled, every entry point brackets its DOMINANT
  * kernel launch with a HIP event pair on the caller's stream.  hmse_profile_read() waits for the
  * recorded events (a host sync — never call it inside a capture), adds their durations to the
  * stage's running total and returns it.  Off by default; not part of the data path.
- * Slots: the HMSE_STAGE_* ids; the six DEFLATE match-kernel size classes report in slots 8..13
+ * Slots: the HMSE_STAGE_* ids (0..31); the six DEFLATE match-kernel size classes report in slots 8..13
  * (S, SG2, SG3, B, S2, SG) and the two encode-kernel instantiations in 14 and 15 (hmse_amd/csrc/l1_deflate.hip).
  */
 void hmse_profile_enable(int on);

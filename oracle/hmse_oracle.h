@@ -9,6 +9,8 @@
  *   - L3 SHA-256: pinned by FIPS 180-4 / hashlib / NIST vectors (tests/test_oracle.py).
  *   - L4a MurmurHash3_x86_32: pinned by the known-answer vectors of SURVEY.md §8c.
  *   - L1 DEFLATE: pinned by RFC 1951 decodability through stock zlib (round trip).
+ *   - L1 inflate (read path): pinned against stock zlib 1.2.11 — same bytes on valid streams, same
+ *     accept/reject decision on mutated ones (tests/test_oracle.py).
  *   - L2 Gear-FastCDC cut points, L4 signatures/LSH bases: PARITY UNPINNED at the
  *     reference; pinned here by an independent pure-Python restatement
  *     (oracle/pyref.py) and committed fixtures (tests/golden/).
@@ -56,6 +58,14 @@ int      orc_deflate_chunks(const uint8_t* data, const uint64_t* cuts, const uin
 /* debug hooks used by the parity tests to localise a mismatch */
 void     orc_deflate_matches(const uint8_t* chunk, uint32_t len, const uint8_t* dict, uint32_t dict_len,
                              const hmse_cfg* cfg, uint16_t* mlen, uint16_t* mdist);
+
+/* read path: raw-DEFLATE decode (RFC 1951; rejected set = stock zlib's, see hmse_oracle_inflate.c); 0 or <0 reason */
+int      orc_inflate(const uint8_t* stream, uint64_t stream_len, const uint8_t* dict, uint32_t dict_len,
+                     uint8_t* out, uint32_t raw_len);
+/* batch form mirroring hmse_l1_inflate; returns the number of corrupt streams, ok[k] = 1 where chunk k decoded */
+uint64_t orc_inflate_chunks(const uint8_t* streams, const uint64_t* stream_off, const uint32_t* stream_len,
+                            const uint8_t* kind, const int64_t* base, uint64_t n_sel, const uint64_t* raw_off,
+                            uint8_t* raw_out, uint8_t* ok);
 
 #ifdef __cplusplus
 }

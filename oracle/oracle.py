@@ -25,7 +25,7 @@ class Cfg(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("hmse_oracle.c", "hmse_oracle_deflate.c", "hmse_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("hmse_oracle.c", "hmse_oracle_deflate.c", "hmse_oracle_inflate.c", "hmse_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -67,6 +67,10 @@ def lib():
         L.orc_deflate_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, cfgp,
                                          C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.orc_deflate_matches.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, cfgp, C.c_void_p, C.c_void_p]
+        L.orc_inflate.restype = C.c_int
+        L.orc_inflate.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_inflate_chunks.restype = C.c_uint64
+        L.orc_inflate_chunks.argtypes = [C.c_void_p] * 5 + [C.c_uint64] + [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -220,3 +224,28 @@ def deflate_chunks(data, cuts, cfg: Cfg, chunk_ids=None, base=None):
     if rc != 0:
         raise RuntimeError(f"orc_deflate_chunks -> {rc}")
     return out[: int(off[n])].copy(), off, kind
+
+
+def inflate(stream, raw_len: int, zdict=None):
+    """Raw-DEFLATE decode; returns (bytes, 0) or (None, negative reason). README.md:2397-2400."""
+    st = _u8(stream)
+    d = _u8(zdict) if zdict is not None and len(zdict) else None
+    out = np.zeros(max(raw_len, 1), dtype=np.uint8)
+    rc = lib().orc_inflate(_p(st), st.size, _p(d), 0 if d is None else d.size, _p(out), raw_len)
+    return (out[:raw_len].tobytes(), 0) if rc == 0 else (None, rc)
+
+
+def inflate_chunks(streams, stream_off, kind, base, raw_len, stream_len=None):
+    """Batch form of hmse_l1_inflate -> (raw bytes, raw_off, ok flags)."""
+    st = _u8(streams)
+    off = np.ascontiguousarray(stream_off, dtype=np.uint64)
+    kd = np.ascontiguousarray(kind, dtype=np.uint8)
+    n = kd.size
+    b = None if base is None else np.ascontiguousarray(base, dtype=np.int64)
+    sl = None if stream_len is None else np.ascontiguousarray(stream_len, dtype=np.uint32)
+    raw_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(raw_len, dtype=np.uint64), out=raw_off[1:])
+    raw = np.zeros(max(int(raw_off[-1]), 1), dtype=np.uint8)
+    ok = np.zeros(max(n, 1), dtype=np.uint8)
+    lib().orc_inflate_chunks(_p(st), _p(off), _p(sl), _p(kd), _p(b), n, _p(raw_off), _p(raw), _p(ok))
+    return raw[: int(raw_off[-1])], raw_off, ok[:n].astype(bool)

@@ -271,3 +271,90 @@ def test_golden_variants_family(orc):
         b = int(uniq[base[k]]); c = int(uniq[k])
         assert _rt(out[int(off[k]):int(off[k + 1])].tobytes(), var[int(cuts[b]):int(cuts[b + 1])].tobytes()) == \
             var[int(cuts[c]):int(cuts[c + 1])].tobytes()
+
+
+# ---------------------------------------------------------------- read path: inflate vs stock zlib (README.md:2397-2400)
+def _zlib_raw_inflate(stream, zd=None):
+    try:
+        d = zlib.decompressobj(-15, zdict=zd) if zd else zlib.decompressobj(-15)
+        out = d.decompress(stream) + d.flush()
+        return out if d.eof and not d.unused_data else None
+    except zlib.error:
+        return None
+
+
+def _zlib_streams():
+    """(payload, dictionary, raw stream) over every block type zlib can emit: stored, fixed, dynamic, multi-block."""
+    rng = np.random.default_rng(0)
+    payloads = [b"", b"a", b"hello hello hello hello", rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(), b"abc" * 5000,
+                rng.integers(97, 101, 20000, dtype=np.uint8).tobytes(), b"\0" * 32768, words_text(32768, seed=3).tobytes()]
+    zdict = words_text(40000, seed=3).tobytes()  # longer than the 32 KiB window: only its tail may be referenced
+    for t in payloads:
+        for lvl in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                for zd in (None, zdict):
+                    c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 9, strat, zdict=zd) if zd else zlib.compressobj(lvl, zlib.DEFLATED, -15, 9, strat)
+                    yield t, zd, c.compress(t[:len(t) // 2]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(t[len(t) // 2:]) + c.flush()
+
+
+def mutate(stream: bytes, rnd) -> bytes:
+    m = bytearray(stream)
+    k = rnd.random()
+    if k < 0.5 and m:
+        m[rnd.randrange(min(len(m), 40))] ^= 1 << rnd.randrange(8)   # headers and code-length sets live up front
+    elif k < 0.7 and m:
+        m[rnd.randrange(len(m))] ^= 1 << rnd.randrange(8)
+    elif k < 0.85:
+        m = m[:rnd.randrange(len(m) + 1)]
+    else:
+        m += b"\0"
+    return bytes(m)
+
+
+def test_inflate_equals_zlib_on_valid_streams(orc):
+    n = 0
+    for t, zd, s in _zlib_streams():
+        got, rc = orc.inflate(s, len(t), zd)
+        assert rc == 0 and got == t, (len(t), rc)
+        n += 1
+    assert n == 8 * 4 * 4 * 2
+
+
+def test_inflate_rejects_exactly_what_zlib_rejects(orc):
+    """Mutated streams: same accept/reject decision as stock zlib 1.2.11 (+ the raw-length contract), same bytes if accepted."""
+    import random
+    rnd = random.Random(1)
+    accepted = rejected = 0
+    for t, zd, s in _zlib_streams():
+        for _ in range(12):
+            m = mutate(s, rnd)
+            want = _zlib_raw_inflate(m, zd)
+            if want is not None and len(want) != len(t):
+                want = None
+            got, rc = orc.inflate(m, len(t), zd)
+            assert (got is None) == (want is None), (len(t), rc)
+            assert got == want
+            accepted += got is not None
+            rejected += got is None
+    assert accepted > 50 and rejected > 1000
+
+
+def test_inflate_chunks_inverts_deflate_chunks(orc, corpus_small):
+    cfg = orc.default_cfg()
+    data = corpus_small[: 600_000]
+    cuts = orc.cdc(data, cfg)
+    n = len(cuts) - 1
+    base = np.full(n, -1, dtype=np.int64)
+    base[3::2] = np.arange(3, n, 2) - 2
+    out, off, kind = orc.deflate_chunks(data, cuts, cfg, None, base)
+    raw, raw_off, ok = orc.inflate_chunks(out, off, kind, base, np.diff(cuts.astype(np.int64)))
+    assert ok.all() and np.array_equal(raw_off, cuts) and np.array_equal(raw, data[: int(cuts[-1])])
+    # a corrupt record poisons the DELTA records that (transitively) use it as dictionary, nothing else
+    k = int(np.nonzero(kind == 2)[0][4]); b = int(base[k])
+    bad = out.copy(); bad[int(off[b])] ^= 0x06  # block type bits of the base's stream -> reserved type 3
+    _, _, ok2 = orc.inflate_chunks(bad, off, kind, base, np.diff(cuts.astype(np.int64)))
+    poisoned = {b}
+    for j in range(n):
+        if kind[j] == 2 and int(base[j]) in poisoned:
+            poisoned.add(j)
+    assert k in poisoned and set(np.nonzero(~ok2)[0].tolist()) == poisoned
