@@ -216,6 +216,36 @@ def main():
                             "frac_hbm": round(gbps / HBM_PEAK_GBPS, 5)}
     dom = max(stage_roof, key=lambda nme: stage_roof[nme]["avg_ms"]) if stage_roof else None
 
+    # read path, outside the timed region: every stored record is inflated on the GPU and its SHA-256
+    # re-checked; on one GPU the whole corpus is also reassembled (pointers included) and compared byte for byte
+    read_info = None
+    if res.streams is not None and res.digests is not None and os.environ.get("HMSE_BENCH_NO_VERIFY") != "1":
+        from hmse_amd import read
+        for s in (16, 17):
+            lib.hmse_profile_read(s, None, None, 1)
+        lib.hmse_profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if world == 1 and not distributed:
+            back = read.reconstruct_shard(res, verify=True)
+            torch.cuda.synchronize()
+            t_read = time.perf_counter() - t0
+            identical = bool(torch.equal(back, data))
+            del back
+            read_info = {"scope": "whole shard: inflate + pointer assembly + SHA-256 of every chunk", "identical_to_input": identical,
+                         "sha256_verified_chunks": st["chunks"], "GiB_per_s": round(n_local / t_read / 2**30, 3), "ms": round(t_read * 1e3, 2)}
+        else:
+            n_ok = read.verify_stored(res)
+            torch.cuda.synchronize()
+            t_read = time.perf_counter() - t0
+            read_info = {"scope": "stored records of rank 0: inflate + SHA-256", "sha256_verified_chunks": n_ok, "ms": round(t_read * 1e3, 2)}
+        lib.hmse_profile_enable(0)
+        for s, nm in ((16, "l1_inflate_kernel_ms"), (17, "assemble_kernel_ms")):
+            ms, n = C.c_double(), C.c_uint64()
+            lib.hmse_profile_read(s, C.byref(ms), C.byref(n), 1)
+            if n.value:
+                read_info[nm] = round(ms.value / n.value, 3)
+
     stats = [st]
     if distributed:
         allst = [None] * world
@@ -244,6 +274,8 @@ def main():
                                "frac": r["frac_hbm"], "traffic": measured_traffic(dom, tot["bytes"], world),
                                "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0"}
         out["stage_roofline"] = stage_roof
+        if read_info:
+            out["read_path"] = read_info
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(host, a.cpu_sample_mib)

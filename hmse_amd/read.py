@@ -40,6 +40,18 @@ def reconstruct_shard(res, verify: bool = True) -> torch.Tensor:
     return data
 
 
+def verify_stored(res) -> int:
+    """Decode every record this shard stores (FULL and DELTA) and re-check its SHA-256 against the L3 digest: the
+    reference's read-side gate (README.md:1329) without the POINTER branch, so it holds on any rank of a sharded run
+    (a pointer's target may live on another GPU).  Returns the number of records verified."""
+    if res.streams is None or res.digests is None:
+        raise ReadError("verify_stored needs the L1 streams and the L3 digests")
+    lens = res.cuts[1:] - res.cuts[:-1]
+    raw, raw_off, _ = ops.l1_inflate(res.streams, res.stream_off, res.kind, res.base, lens[res.uniq_ids])
+    verify_digests(raw, raw_off, res.digests[res.uniq_ids])
+    return int(res.uniq_ids.numel())
+
+
 def verify_digests(data: torch.Tensor, cuts: torch.Tensor, digests: torch.Tensor) -> None:
     got = ops.l3_sha256(data, cuts)
     if not torch.equal(got, digests):
