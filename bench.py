@@ -108,6 +108,11 @@ def measured_traffic(kernel: str, total_bytes: int, world: int):
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner there at its
+    # first collective) are sent to stderr for the whole run, and the result is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from hmse_amd import ABLATIONS, IngestConfig, _lib, corpus, ingest, ops
@@ -281,7 +286,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(host, a.cpu_sample_mib)
             except Exception as e:  # noqa: BLE001 — the baseline leg must not lose the GPU measurement
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
