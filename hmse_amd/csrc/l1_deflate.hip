@@ -324,6 +324,7 @@ struct Args {
   const uint8_t* data; uint64_t n;
   const uint64_t* cuts; const uint64_t* chunk_ids; const int64_t* base; uint64_t n_sel;
   uint32_t depth;
+  uint32_t base_is_chunk;    // base[] holds chunk indices (into cuts) instead of indices into the selection
   const uint64_t* rec_off;   // [n_sel] byte offset of chunk k's record pair (FULL, then DELTA at + rec_size(L))
   uint8_t* recs;
   uint64_t rec_cap; uint32_t* status;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     uint32_t Dl = 0; uint64_t dstart = 0;
     if (variant == 1) {
       const int64_t bsel = a.base[k];
-      const uint64_t bc = a.chunk_ids ? a.chunk_ids[bsel] : (uint64_t)bsel;
+      const uint64_t bc = (a.chunk_ids && !a.base_is_chunk) ? a.chunk_ids[bsel] : (uint64_t)bsel;
       dstart = a.cuts[bc];
       uint64_t dl64 = a.cuts[bc + 1] - dstart;
       if (dl64 > WMAX) { dstart += dl64 - WMAX; dl64 = WMAX; }
@@ -904,7 +905,7 @@ static_assert(2 * Layout<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>::TOTA
 
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
-                                                        const int64_t* __restrict__ base, uint64_t n_sel,
+                                                        const int64_t* __restrict__ base, uint64_t n_sel, uint32_t base_is_chunk,
                                                         uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts) {
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // wave-aggregated append (one atomic per class per wavefront instead of one per job)
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
     const uint64_t c = chunk_ids ? chunk_ids[k] : k;
     L = cuts[c + 1] - cuts[c];
     if (base && base[k] >= 0) {
-      const uint64_t bc = chunk_ids ? chunk_ids[base[k]] : (uint64_t)base[k];
+      const uint64_t bc = (chunk_ids && !base_is_chunk) ? chunk_ids[base[k]] : (uint64_t)base[k];
       Dl = cuts[bc + 1] - cuts[bc];
       if (Dl > WMAX) Dl = WMAX;
       hasb = true;
@@ -1108,11 +1109,14 @@ extern "C" int hmse_debug_deflate_stamps(unsigned long long* out48, int reset) {
 // fixed part only; the caller adds the slot area: sum over chunks of align16(len+5) * (1 + has_base)
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_sel, const hmse_cfg*) { return dfl::carve(nullptr, n_sel).fixed_bytes; }
 
-extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
-                               const int64_t* base, uint64_t n_sel, const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap,
-                               uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
+                                  const int64_t* base, uint64_t n_sel, const hmse_cfg* cfg, uint32_t flags, uint8_t* out,
+                                  uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes,
+                                  void* stream_) {
   using namespace dfl;
   if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
+  if (flags & ~(uint32_t)HMSE_DEFLATE_BASE_IS_CHUNK_ID) return HMSE_EINVAL;
+  const uint32_t a_base_is_chunk = (flags & HMSE_DEFLATE_BASE_IS_CHUNK_ID) ? 1u : 0u;
   if (!out_off || !status) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
@@ -1132,11 +1136,12 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
   rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off);
   HMSE_LAUNCH_CHECK();
   if (exclusive_scan_u64(w.rec_off, n_sel, w.rec_off, w.bsum, w.rec_total, stream) != HMSE_OK) return HMSE_EHIP;
-  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.lists, w.list_stride, w.counters);
+  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, a_base_is_chunk, w.lists, w.list_stride, w.counters);
   HMSE_LAUNCH_CHECK();
   Args a;
   a.data = data; a.n = n; a.cuts = cuts; a.chunk_ids = chunk_ids; a.base = base; a.n_sel = n_sel;
   a.depth = hmse_deflate_depth(cfg);
+  a.base_is_chunk = a_base_is_chunk;
   a.rec_off = w.rec_off; a.recs = w.recs; a.len_full = w.len_full; a.len_delta = w.len_delta;
   a.rec_cap = avail; a.status = status;
   a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
@@ -1197,4 +1202,10 @@ extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* 
                                                                 out_cap, status);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
+}
+
+extern "C" int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
+                               const int64_t* base, uint64_t n_sel, const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap,
+                               uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream_) {
+  return hmse_l1_deflate_ex(data, n, cuts, chunk_ids, base, n_sel, cfg, 0u, out, out_cap, out_off, kind, status, ws, ws_bytes, stream_);
 }

@@ -153,8 +153,9 @@ def l4_lsh(sig: torch.Tensor, cfg: IngestConfig):
 
 
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
-               base: torch.Tensor | None = None):
-    """Per-chunk raw DEFLATE with the base chunk as dictionary.
+               base: torch.Tensor | None = None, base_is_chunk_id: bool = False):
+    """Per-chunk raw DEFLATE with the base chunk as dictionary (`base`: index into the selection, or — with
+    base_is_chunk_id — a chunk index into `cuts`, e.g. a chunk stored by an earlier batch of a stream).
 
     Returns (out uint8[total], out_off int64[n_sel+1], kind uint8[n_sel]). README.md:2374-2378, 2182-2189."""
     _require_gpu(data, "data")
@@ -176,9 +177,9 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     c = cfg.to_c()
     nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
     ws = _ws(nb + need + 4096, dev)
-    rc = _lib.hip_lib().hmse_l1_deflate(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
-                                        _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status), ws.data_ptr(), ws.numel(),
-                                        _stream())
+    rc = _lib.hip_lib().hmse_l1_deflate_ex(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
+                                           1 if base_is_chunk_id else 0, _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status),
+                                           ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_l1_deflate")
     total = int(out_off[-1].item())
     if int(status.item()):

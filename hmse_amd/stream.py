@@ -1,0 +1,104 @@
+"""Streaming front end (BASELINE.json configs[4]): the corpus arrives in batches, host -> HBM copies of
+batch k+1 overlap the kernels of batch k, and the index persists across batches.
+
+Every batch runs the same C-ABI stages as ingest_shard; what persists between batches lives in HBM:
+  * the raw bytes of everything ingested so far (288 GB of HBM hold the whole 4 x 10 GB configuration), so a chunk of
+    an earlier batch can serve as DEFLATE dictionary for a later one (hmse_l1_deflate_ex, HMSE_DEFLATE_BASE_IS_CHUNK_ID);
+  * all cut points, digests (the L3 index of README.md:1263-1270 — first occurrences are GLOBAL over the stream),
+    signatures of the stored chunks (the L4 band tables are rebuilt from them; a base is the earliest stored chunk that
+    shares a band, whichever batch it came from).
+With batches that are whole multiples of the segment size, every output equals what ingest_shard returns for the
+concatenated input, bit for bit (tests/test_gpu_stream.py) — batching is a schedule, not a different result.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import LAYER_L1, LAYER_L2, LAYER_L3, LAYER_L4, IngestConfig
+from .ingest import ShardResult, shard_stats
+
+
+class StreamIngest:
+    def __init__(self, cfg: IngestConfig, capacity_bytes: int, device):
+        if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
+            raise ValueError("StreamIngest runs the full L1-L4 pipeline")
+        self.cfg, self.dev = cfg, device
+        self.data = torch.empty(int(capacity_bytes), dtype=torch.uint8, device=device)
+        self.n_bytes = 0            # bytes whose host -> HBM copy has been issued
+        self.n_done = 0             # bytes processed
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.pending: list[tuple[int, int, torch.cuda.Event]] = []   # (offset, length, copy-done event)
+        z64 = lambda n: torch.zeros(n, dtype=torch.int64, device=device)
+        self.cuts = z64(1)
+        self.digests = torch.empty((0, 32), dtype=torch.uint8, device=device)
+        self.uniq_ids = z64(0)      # global chunk index of every stored chunk, ascending
+        self.sig = torch.empty((0, cfg.n_hashes), dtype=torch.int32, device=device)
+        self.base = z64(0)          # per stored chunk: slot of its dictionary chunk or -1
+        self.kind = torch.empty(0, dtype=torch.uint8, device=device)
+        self.stream_off = z64(1)
+        self.stream_parts: list[torch.Tensor] = []
+        self.first_occ = z64(0)
+        self.refcount = torch.empty(0, dtype=torch.int32, device=device)
+        self.band_keys = torch.empty((0, cfg.bands), dtype=torch.int32, device=device)
+
+    # ------------------------------------------------------------------ feeding
+    def push(self, host_batch: torch.Tensor) -> None:
+        """Issue the host -> HBM copy of the next batch (asynchronous when the tensor is pinned), then process every
+        batch whose copy was issued earlier: the copy of this batch overlaps the kernels of the previous one."""
+        n = host_batch.numel()
+        if self.n_bytes % self.cfg.seg_size:
+            raise ValueError("only the last batch may be a partial segment")
+        if self.n_bytes + n > self.data.numel():
+            raise ValueError("stream capacity exceeded")
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.copy_stream):
+            self.data[self.n_bytes: self.n_bytes + n].copy_(host_batch, non_blocking=True)
+            ev.record(self.copy_stream)
+        while self.pending:  # batches issued before this one
+            self._process(*self.pending.pop(0))
+        self.pending.append((self.n_bytes, n, ev))
+        self.n_bytes += n
+
+    def finish(self) -> ShardResult:
+        while self.pending:
+            self._process(*self.pending.pop(0))
+        streams = torch.cat(self.stream_parts) if self.stream_parts else torch.empty(0, dtype=torch.uint8, device=self.dev)
+        res = ShardResult(self.n_done, self.cuts, self.digests, 0, self.cuts.numel() - 1, self.first_occ, self.refcount, self.uniq_ids,
+                          self.sig, self.band_keys, self.base, streams, self.stream_off, self.kind)
+        res.stats = shard_stats(res)
+        return res
+
+    # ------------------------------------------------------------------ one batch
+    def _process(self, off: int, n: int, copied: torch.cuda.Event) -> None:
+        cfg, dev = self.cfg, self.dev
+        torch.cuda.current_stream().wait_event(copied)
+        batch = self.data[off: off + n]
+        all_data = self.data[: off + n]
+        # L2 on the batch (segments restart at batch-local multiples of seg_size == global ones), offsets made global
+        cuts_b = ops.l2_cdc(batch, cfg) + off
+        n_old = self.cuts.numel() - 1
+        self.cuts = torch.cat([self.cuts, cuts_b[1:]])
+        n_new = cuts_b.numel() - 1
+        # L3: digests of the new chunks, first occurrences over the whole stream
+        dig_b = ops.l3_sha256(all_data, self.cuts[n_old:])
+        self.digests = torch.cat([self.digests, dig_b])
+        self.first_occ, self.refcount = ops.l3_dedup(self.digests)
+        idx_new = torch.arange(n_old, n_old + n_new, dtype=torch.int64, device=dev)
+        uniq_new = idx_new[self.first_occ[n_old:] == idx_new]
+        u_old = self.uniq_ids.numel()
+        self.uniq_ids = torch.cat([self.uniq_ids, uniq_new])
+        # L4: signatures of the new stored chunks; bases over every stored chunk so far (earliest sharer wins, so the
+        # bases of earlier slots never change and only the tail is new)
+        sig_b = ops.l4_minhash(all_data, self.cuts, cfg, uniq_new)
+        self.sig = torch.cat([self.sig, sig_b])
+        self.band_keys, base_all = ops.l4_lsh(self.sig, cfg)
+        base_new = base_all[u_old:]
+        self.base = torch.cat([self.base, base_new])
+        # L1: the dictionary may be a chunk of an earlier batch -> bases as chunk indices
+        base_chunk = torch.where(base_new >= 0, self.uniq_ids[base_new.clamp(min=0)], base_new)
+        streams_b, off_b, kind_b = ops.l1_deflate(all_data, self.cuts, cfg, uniq_new, base_chunk, base_is_chunk_id=True)
+        self.stream_parts.append(streams_b)
+        self.stream_off = torch.cat([self.stream_off, off_b[1:] + self.stream_off[-1]])
+        self.kind = torch.cat([self.kind, kind_b])
+        self.n_done = off + n

@@ -180,6 +180,17 @@ int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * L1 with options (the streaming front end): as hmse_l1_deflate, plus
+ *   flags  HMSE_DEFLATE_BASE_IS_CHUNK_ID: base[k] is a chunk index into `cuts` (any chunk of the resident data, e.g. one
+ *          stored by an earlier batch) instead of an index into the selection.
+ */
+enum { HMSE_DEFLATE_BASE_IS_CHUNK_ID = 1u };
+int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
+                       const int64_t* base, uint64_t n_sel, const hmse_cfg* cfg, uint32_t flags, uint8_t* out,
+                       uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/*
  * Read path, L1 — raw DEFLATE decode of stored chunks.  Replaces mz_inflateInit2(&s, 15) + mz_inflate(&s, MZ_FINISH)
  * (README.md:2397-2400) and the FULL / DELTA branches of the read path (README.md:1635-1669, 2191-2198): a DELTA
  * record inflates with the raw bytes of its base chunk as preset dictionary (the last 32 KiB of them).

@@ -1,0 +1,63 @@
+"""GPU: the streaming front end — batches with overlapped host->HBM copies and a persistent index must
+give exactly what one ingest_shard call gives for the concatenated input, and read back to the input."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _dataset():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import corpus
+    a = corpus.wiki_synth(4 << 20, seed=42)
+    # later batches repeat and vary the first one: cross-batch exact duplicates (POINTER) and near-duplicates (DELTA)
+    v = variants_dataset(a)
+    return np.concatenate([a, v, corpus.wiki_synth((12 << 20) - a.size - v.size, seed=7), a[: (1 << 20) + 12345]])
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_stream_equals_single_shot(dev, pinned):
+    import torch
+    from hmse_amd import IngestConfig, ingest, read, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    st = stream.StreamIngest(cfg, data.size, dev)
+    assert data.size > (11 << 20)
+    bounds = [0, 4 << 20, 6 << 20, 11 << 20, data.size]          # uneven batches, the last one a partial segment
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = torch.from_numpy(data[a:b].copy())
+        st.push(h.pin_memory() if pinned else h)
+    res = st.finish()
+    for name in ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams"):
+        assert torch.equal(getattr(res, name), getattr(whole, name)), name
+    assert res.stats == whole.stats
+    # dictionaries and pointers cross batch boundaries
+    b1 = int((res.cuts <= (4 << 20)).sum()) - 1                   # chunks of the first batch
+    slot_chunk = res.uniq_ids
+    crossing = (res.base >= 0) & (slot_chunk >= b1) & (slot_chunk[res.base.clamp(min=0)] < b1) & (res.kind == 2)
+    assert int(crossing.sum()) > 10
+    later = torch.arange(res.first_occ.numel(), device=dev) >= b1
+    assert int(((res.first_occ < b1) & later).sum()) > 10
+    # and the read path returns the input
+    assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))
+
+
+def test_stream_rejects_misaligned_batches(dev):
+    import torch
+    from hmse_amd import IngestConfig, stream
+    st = stream.StreamIngest(IngestConfig(seg_size=1 << 20), 4 << 20, dev)
+    st.push(torch.zeros((1 << 20) + 5, dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        st.push(torch.zeros(1 << 20, dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        stream.StreamIngest(IngestConfig(seg_size=1 << 20), 1 << 20, dev).push(torch.zeros(2 << 20, dtype=torch.uint8))
