@@ -59,10 +59,10 @@ def verify_digests(data: torch.Tensor, cuts: torch.Tensor, digests: torch.Tensor
         raise ReadError(f"SHA-256 mismatch on {bad} of {digests.shape[0]} reconstructed chunks")
 
 
-def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
-    """Manifest bytes (hmse_amd/manifest.py record formats) -> original data, decoded on `device`."""
+def parse_manifest(m: Manifest) -> dict:
+    """Host-side decode of the record headers: per stored slot its kind, dictionary slot, stream position inside the blob and raw length."""
     idx, cmap = m.index, m.chunk_map
-    u, n = len(idx), len(cmap)
+    u = len(idx)
     own = cmap["kind"] != KIND_POINTER
     slot_kind = np.zeros(u, np.uint8)
     slot_kind[cmap["slot"][own]] = cmap["kind"][own]
@@ -83,11 +83,19 @@ def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
             raise ReadError("a DeltaChunk header names an LBA that is not in the index")
         base[is_delta] = order[pos]
         s_len[is_delta] = hdr[:, 1] >> 16
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
-    raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(s_off, torch.int64), t(slot_kind, torch.uint8), t(base, torch.int64),
-                                     t(raw_len, torch.int64), stream_len=t(s_len, torch.int32))
+    return {"kind": slot_kind, "base": base, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
+
+
+def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
+    """Manifest bytes (hmse_amd/manifest.py record formats) -> original data, decoded on `device`."""
+    idx, cmap = m.index, m.chunk_map
+    u, n = len(idx), len(cmap)
+    p = parse_manifest(m)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
+    raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(p["stream_off"], torch.int64), t(p["kind"], torch.uint8), t(p["base"], torch.int64),
+                                     t(p["raw_len"], torch.int64), stream_len=t(p["stream_len"], torch.int32))
     cuts = torch.zeros(n + 1, dtype=torch.int64, device=device)
-    torch.cumsum(t(raw_len[cmap["slot"]], torch.int64), 0, out=cuts[1:])
+    torch.cumsum(t(p["raw_len"][cmap["slot"]], torch.int64), 0, out=cuts[1:])
     data = ops.read_assemble(cuts, t(cmap["slot"].astype(np.int64), torch.int64), raw_off, raw)
     if verify and u and idx["sha256"].any():
         verify_digests(data, cuts, t(idx["sha256"][cmap["slot"]], torch.uint8))

@@ -42,6 +42,49 @@ class StreamIngest:
         self.refcount = torch.empty(0, dtype=torch.int32, device=device)
         self.band_keys = torch.empty((0, cfg.bands), dtype=torch.int32, device=device)
 
+    @staticmethod
+    def resume(m, cfg: IngestConfig, capacity_bytes: int, device) -> "StreamIngest":
+        """Incremental ingest against an existing store: the manifest is read back on the GPU (every record
+        inflated, every chunk's SHA-256 re-checked), which restores the raw bytes in HBM; cut points, digests and kinds come
+        from its records, signatures and bases are recomputed from the restored bytes.  Batches pushed afterwards dedupe and
+        delta against the restored chunks exactly as if the whole history had been one stream."""
+        import numpy as np
+        from . import read
+        st = StreamIngest(cfg, capacity_bytes, device)
+        data = read.read_manifest(m, device, verify=True)
+        n = data.numel()
+        if n % cfg.seg_size:
+            raise ValueError("the stored stream ends inside a segment: nothing can be appended to it")
+        if n > st.data.numel():
+            raise ValueError("stream capacity exceeded")
+        st.data[:n] = data
+        p = read.parse_manifest(m)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
+        st.cuts = torch.zeros(len(m.chunk_map) + 1, dtype=torch.int64, device=device)
+        torch.cumsum(t(p["raw_len"][m.chunk_map["slot"]], torch.int64), 0, out=st.cuts[1:])
+        st.digests = t(m.index["sha256"][m.chunk_map["slot"]], torch.uint8)
+        st.first_occ, st.refcount = ops.l3_dedup(st.digests)
+        idx = torch.arange(st.first_occ.numel(), dtype=torch.int64, device=device)
+        st.uniq_ids = idx[st.first_occ == idx]
+        if st.uniq_ids.numel() != len(m.index):
+            raise ValueError("manifest index and chunk map disagree on the stored chunks")
+        st.sig = ops.l4_minhash(st.data[:n], st.cuts, cfg, st.uniq_ids)
+        st.band_keys, st.base = ops.l4_lsh(st.sig, cfg)
+        st.kind = t(p["kind"], torch.uint8)
+        # dense copy of the stored streams (the blob aligns records to lba_unit and prefixes DELTA records with a header)
+        s_len = t(p["stream_len"], torch.int64)
+        st.stream_off = torch.zeros(s_len.numel() + 1, dtype=torch.int64, device=device)
+        torch.cumsum(s_len, 0, out=st.stream_off[1:])
+        src = torch.arange(int(st.stream_off[-1].item()), dtype=torch.int64, device=device) + \
+            torch.repeat_interleave(t(p["stream_off"], torch.int64) - st.stream_off[:-1], s_len)
+        st.stream_parts = [t(m.blob, torch.uint8)[src]]
+        # the records must agree with what this build derives from the restored bytes
+        mb = t(p["base"], torch.int64)
+        if not bool(((st.kind != 2) | (mb == st.base)).all()):
+            raise ValueError("a DELTA record's dictionary is not the LSH base of its chunk under this configuration")
+        st.n_bytes = st.n_done = n
+        return st
+
     # ------------------------------------------------------------------ feeding
     def push(self, host_batch: torch.Tensor) -> None:
         """Issue the host -> HBM copy of the next batch (asynchronous when the tensor is pinned), then process every

@@ -61,3 +61,23 @@ def test_stream_rejects_misaligned_batches(dev):
         st.push(torch.zeros(1 << 20, dtype=torch.uint8))
     with pytest.raises(ValueError):
         stream.StreamIngest(IngestConfig(seg_size=1 << 20), 1 << 20, dev).push(torch.zeros(2 << 20, dtype=torch.uint8))
+
+
+def test_resume_from_manifest_then_append(dev):
+    """Store A, keep only its manifest bytes, resume from them (GPU read-back restores the history), append B: every output
+    equals one ingest of A+B — incremental ingest against an existing index."""
+    import torch
+    from hmse_amd import IngestConfig, ingest, manifest, read, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    split = 6 << 20
+    first = ingest.ingest_shard(torch.from_numpy(data[:split]).to(dev), cfg)
+    blob = manifest.build_manifest(first).to_bytes()
+    del first
+    st = stream.StreamIngest.resume(manifest.Manifest.from_bytes(blob), cfg, data.size, dev)
+    st.push(torch.from_numpy(data[split:].copy()))
+    res = st.finish()
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    for name in ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams"):
+        assert torch.equal(getattr(res, name), getattr(whole, name)), name
+    assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))

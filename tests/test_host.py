@@ -97,3 +97,33 @@ def test_fixed_cuts_for_l1_only_ablation():
     so = torch.tensor([0, 100_000, 100_000, 170_000])
     c = ingest.fixed_cuts(170_000, cfg, so).tolist()
     assert c[0] == 0 and c[-1] == 170_000 and 100_000 in c and max(np.diff(c)) <= cfg.max_size
+
+
+def test_band_tables_on_disk_round_trip(orc):
+    """README.md:1937-1945 bucket lists: every id sits in the bucket its key names, in ingest order; the LSH base of a
+    chunk is the earliest member of one of its buckets; crowded buckets continue across headers."""
+    from hmse_amd import bandtable
+    rng = np.random.default_rng(3)
+    cfg = orc.default_cfg()
+    n = 3000
+    sig = rng.integers(0, 2**32, (n, 128), dtype=np.uint64).astype(np.uint32)
+    sig[500:900, :32] = sig[17, :32]            # a crowded bucket in band 0
+    sig[1200:1260, 96:] = sig[40, 96:]          # and one in band 3
+    keys, base = orc.lsh(sig, cfg)
+    buf = bandtable.write_band_tables(keys, 16)
+    bits, tables = bandtable.read_band_tables(buf)
+    assert bits == 16 and len(tables) == 4
+    assert len(buf) == 8 + 24 + sum(8 + 4 * len(t[0]) + 3 * n for t in tables)   # 4 B per bucket + 3 B per id per band
+    for b, (h, start, cnt, ids) in enumerate(tables):
+        assert cnt.sum() == n and (np.diff(h.astype(np.int64)) > 0).all()
+        for j in (0, len(h) // 2, len(h) - 1):
+            members = ids[start[j]: start[j] + cnt[j]]
+            assert ((keys[members, b] & 0xFFFF) == h[j]).all() and (np.diff(members.astype(np.int64)) > 0).all()
+    for i in np.nonzero(base >= 0)[0][:200]:
+        firsts = [bandtable.candidates(tables, b, int(keys[i, b] & 0xFFFF)) for b in range(4)]
+        assert any(base[i] in f for f in firsts) and base[i] < i
+    assert base[600] == 17 and bandtable.candidates(tables, 0, int(keys[17, 0] & 0xFFFF))[0] <= 17
+    # > 65535 ids in one bucket: continuation headers
+    big = np.zeros((70000, 4), np.uint32); big[:, 1] = np.arange(70000)
+    _, t2 = bandtable.read_band_tables(bandtable.write_band_tables(big, 16))
+    assert t2[0][2].tolist() == [70000] and np.array_equal(bandtable.candidates(t2, 0, 0), np.arange(70000))
