@@ -8,13 +8,18 @@
 //   1. 4-byte hash (12 bits) of every window position; positions bucket-sorted (counting sort by
 //      LDS atomics + in-bucket rank) so that a position's candidates are its D predecessors in
 //      its bucket: no pointer chasing, contiguous reads;
-//   2. every chunk position finds its longest match in parallel (one lane per position);
-//   3. the one-step-lazy parse p -> next(p) is a functional graph: reachable positions are marked
-//      by pointer doubling (log rounds) instead of a serial walk;
-//   4. histograms by LDS atomics, length-limited Huffman (sorted two-queue merge + Kraft repair),
-//      closed-form code-length RLE, smallest of stored/fixed/dynamic;
-//   5. token bit offsets by a workgroup prefix scan, bits OR-ed into an LDS image, coalesced copy-out.
-// One workgroup per job (chunk, or chunk+dictionary); persistent workgroups pull jobs from a counter.
+//   2. every chunk position finds its longest match in parallel (lanes are small state machines that pull the next
+//      sorted rank when they finish one);
+//   3. the one-step-lazy parse p -> next(p) is a functional graph: every wavefront walks its own segment
+//      speculatively (a chain of v_readlane inside 64-position windows), wave 0 stitches the segments where
+//      the chains meet;
+//   4. tokens compacted in parse order + symbol histograms (LDS atomics) -> a job record in HBM     [match kernel]
+//   5. length-limited Huffman (sorted two-queue merge + Kraft repair), closed-form code-length RLE, smallest of
+//      stored/fixed/dynamic; token bit offsets by prefix scans, bits OR-ed into an LDS image, coalesced
+//      copy-out                                                                                      [encode kernel]
+// Match kernel: one 512/1024-thread workgroup per job (chunk, or chunk + dictionary), size classes by window
+// length; encode kernel: one 256-thread workgroup per job, six per CU.  Persistent workgroups pull jobs from
+// per-class lists.
 #include "common.h"
 
 namespace dfl {
@@ -348,8 +353,6 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
   uint32_t* const cur = (uint32_t*)(smem + LY::CUR_OFF);
-  HuffL* const hsL = (HuffL*)(smem + LY::CUR_OFF);
-  HuffD* const hsD = (HuffD*)(smem + LY::CUR_OFF + sizeof(HuffL));
   uint32_t* const mark = (uint32_t*)(smem + LY::MARK_OFF);
   Small<NT>& sm = *(Small<NT>*)(smem + LY::SMALL_OFF);
   Scratch* const sc = LDSM ? nullptr : (Scratch*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
@@ -896,7 +899,6 @@ __global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
 constexpr int NT_M = 1024, TCAP_SG3 = 32768;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_CLASS = 7;      // match-kernel size classes
 constexpr int N_LIST = 9;       // + two encode-kernel lists (by chunk length): lists 6 and 7; class SG2 is list 8
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");

@@ -49,7 +49,7 @@ constexpr int L2_NT = 256;                     // threads per workgroup
 #endif
 constexpr int L2_STRIP = HMSE_L2_STRIP;          // bytes per lane
 constexpr int L2_TILE = L2_NT * L2_STRIP;      // 32 KiB of input per workgroup
-constexpr int L2_PSTRIDE = L2_STRIP + 16;      // padded strip pitch: ds_read_b128 conflict-free
+[[maybe_unused]] constexpr int L2_PSTRIDE = L2_STRIP + 16;  // staged variant only: padded strip pitch, ds_read_b128 conflict-free
 constexpr int L2_COPIES = HMSE_L2_COPIES;        // Gear table replicas: 1 measured best (occupancy beats bank spreading)
 constexpr int L2_WORDS = L2_STRIP / 32;        // bitmap dwords per lane
 

@@ -35,12 +35,12 @@ Tdelta = (lens + torch.clamp(lens[base.clamp(min=0)], max=32768))[hb]
 allT = torch.cat([Tfull, Tdelta]).cpu().numpy()
 allL = torch.cat([lens, lens[hb]]).cpu().numpy()
 import numpy as _np
-cls_ = _np.where(allT <= 9216, 0, _np.where(allT <= 12288, 4, _np.where(allT <= 20480, 1, _np.where((allT <= 26624) & (allL <= 13312), 2, 3))))
-for ci_, nm in enumerate(("S", "MF", "MD", "B", "S2")):
+cls_ = _np.where(allT <= 9216, 0, _np.where(allT <= 12288, 1, _np.where(allT <= 16000, 2, _np.where(allT <= 21504, 3, _np.where(allT <= 32768, 4, 5)))))
+for ci_, nm in enumerate(("S", "S2", "SG", "SG2", "SG3", "B")):
     m_ = cls_ == ci_
     print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
-for c, cn in enumerate(["small", "medium", "big"]):
+for c, cn in enumerate(["classes with T <= 9216 (S)", "the other LDS classes (S2, SG, SG2, SG3)", "big (B)"]):
     row = buf[c * 16:(c + 1) * 16].astype(np.float64)
     tot = row.sum()
     if tot == 0:
