@@ -127,3 +127,33 @@ def test_band_tables_on_disk_round_trip(orc):
     big = np.zeros((70000, 4), np.uint32); big[:, 1] = np.arange(70000)
     _, t2 = bandtable.read_band_tables(bandtable.write_band_tables(big, 16))
     assert t2[0][2].tolist() == [70000] and np.array_equal(bandtable.candidates(t2, 0, 0), np.arange(70000))
+
+
+def test_parse_manifest_matches_the_oracle_records(orc):
+    """Host half of the GPU read path (hmse_amd/read.py): kinds, dictionary slots, stream positions and raw lengths decoded
+    from the packed records equal what the writer was given; the oracle inflate decodes them to the input."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import corpus, manifest, read
+    data = variants_dataset(corpus.wiki_synth(3 << 20, seed=42))
+    res = _shard_result_from_oracle(orc, data, {"seg_size": 1 << 20})
+    m = manifest.Manifest.from_bytes(manifest.build_manifest(res).to_bytes())
+    p = read.parse_manifest(m)
+    kind, base = res.kind.numpy(), res.base.numpy()
+    off = res.stream_off.numpy()
+    assert np.array_equal(p["kind"], kind)
+    assert np.array_equal(p["base"], np.where(kind == 2, base, -1))
+    assert np.array_equal(p["stream_len"], np.diff(off))
+    lens = np.diff(res.cuts.numpy())
+    assert np.array_equal(p["raw_len"], lens[res.uniq_ids.numpy()])
+    raw, raw_off, ok = orc.inflate_chunks(m.blob, p["stream_off"], p["kind"], p["base"], p["raw_len"], stream_len=p["stream_len"])
+    assert ok.all()
+    want = np.concatenate([data[int(res.cuts[i]):int(res.cuts[i + 1])] for i in res.uniq_ids.tolist()])
+    assert np.array_equal(raw, want)
+    # a header that names an LBA outside the index is refused
+    bad = m.blob.copy()
+    k = int(np.nonzero(kind == 2)[0][0]); o = int(m.index["lba"][k]) * m.lba_unit
+    bad[o:o + 4] = np.frombuffer(np.uint32(0xFFFFFFF0).tobytes(), np.uint8)
+    with pytest.raises(read.ReadError):
+        read.parse_manifest(manifest.Manifest(m.lba_unit, m.index, m.chunk_map, m.pointers, bad))
