@@ -86,7 +86,7 @@ struct Small {
   uint32_t red[NT / 64 + 1];
   uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
   uint32_t job, qhead;
-  uint32_t pexit[NT / 64];
+  uint32_t pexit[NT / 64], pexit2[NT / 64], pconv[NT / 64];
 };
 
 constexpr int align16(int v) { return (v + 15) & ~15; }
@@ -592,41 +592,65 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
             m |= 1ull << (curp - wb);
             curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
           }
-          if (lane == 0) { mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32); }
+          mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32);  // every lane, same words (no lane-dependent branch at a loop tail)
         }
-        if (lane == 0) sm.pexit[wave] = curp;
+        sm.pexit[wave] = curp;  // every lane, same value
+      }
+      __syncthreads();
+      // Stitch segment w from its true entry e: windows wholly before e hold no true position; from e's window on every
+      // window is rewritten (a long match may jump over whole windows, whose speculative marks must go too) until the
+      // walk meets a speculatively marked position, whose marks are kept from there on.  Returns the segment's true exit.
+      // `chain_exit` = exit of the chain the segment's marks currently describe (returned when the walk meets it).
+      auto stitch = [&](uint32_t w, uint32_t e, uint32_t chain_exit, bool intact, bool& conv_out) -> uint32_t {
+        const uint32_t sw = w * SEG;
+        const uint32_t send = (sw + SEG) < L ? (sw + SEG) : L;
+        conv_out = true;
+        if (intact && e == sw) return chain_exit;  // the speculation started at the true entry (marks untouched so far)
+        for (uint32_t wb = sw; wb < send && (wb + 64 <= e || e >= send); wb += 64)
+          { mark[wb >> 5] = 0; mark[(wb >> 5) + 1] = 0; }
+        uint32_t curp = e;
+        bool conv = false;
+        for (uint32_t wb = e & ~63u; wb < send && !conv; wb += 64) {
+          const uint32_t x = wb + lane;
+          const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
+          const uint64_t spec = (uint64_t)mark[wb >> 5] | ((uint64_t)mark[(wb >> 5) + 1] << 32);
+          const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
+          uint64_t m = 0;
+          while (curp < wend) {
+            if ((spec >> (curp - wb)) & 1ull) { conv = true; break; }
+            m |= 1ull << (curp - wb);
+            curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
+          }
+          if (conv) m |= spec & ~((1ull << (curp - wb)) - 1ull);  // speculative marks from the meeting point on
+          mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32);  // every lane, same words (no lane-dependent branch at a loop tail)
+        }
+        conv_out = conv;
+        return conv ? chain_exit : curp;
+      };
+      // Second-level speculation: chains almost always meet inside a segment, and then the segment's exit is the
+      // speculative one — so every wavefront stitches ITS segment at once, taking the previous segment's speculative exit
+      // as entry.  Segment w's result is final iff all segments before it met their speculative chain; from the first
+      // one that did not, wave 0 redoes the rest in order (the marks left by a stitch from a wrong entry are still
+      // one successor-closed chain with exit pexit2[w], which is all the stitch relies on).
+      {
+        const uint32_t sw = wave * SEG;
+        bool conv = true;
+        uint32_t ex = sm.pexit[wave];
+        if (wave > 0 && sw < L) ex = stitch(wave, sm.pexit[wave - 1], sm.pexit[wave], true, conv);
+        wave_sync();
+        sm.pexit2[wave] = ex; sm.pconv[wave] = (wave == 0 || sw >= L || conv) ? 1u : 0u;
       }
       __syncthreads();
       if (wave == 0) {
-        uint32_t tru = sm.pexit[0];  // true exit of the segments stitched so far
-        for (uint32_t w = 1; w < NW; w++) {
-          const uint32_t sw = w * SEG;
-          if (sw >= L) break;
-          const uint32_t send = (sw + SEG) < L ? (sw + SEG) : L;
-          const uint32_t e = tru;
-          if (e == sw) { tru = sm.pexit[w]; continue; }  // the speculation started at the true entry
-          // windows that lie wholly before the true entry hold no true position
-          for (uint32_t wb = sw; wb < send && (wb + 64 <= e || e >= send); wb += 64)
-            if (lane == 0) { mark[wb >> 5] = 0; mark[(wb >> 5) + 1] = 0; }
-          uint32_t curp = e;
-          bool conv = false;
-          // every window from the entry's on is rewritten (a long match may jump over whole windows,
-          // whose speculative marks must go too) until the two chains meet
-          for (uint32_t wb = e & ~63u; wb < send && !conv; wb += 64) {
-            const uint32_t x = wb + lane;
-            const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
-            const uint64_t spec = (uint64_t)mark[wb >> 5] | ((uint64_t)mark[(wb >> 5) + 1] << 32);
-            const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
-            uint64_t m = 0;
-            while (curp < wend) {
-              if ((spec >> (curp - wb)) & 1ull) { conv = true; break; }
-              m |= 1ull << (curp - wb);
-              curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
-            }
-            if (conv) m |= spec & ~((1ull << (curp - wb)) - 1ull);  // speculative marks from the meeting point on
-            if (lane == 0) { mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32); }
+        uint32_t first_bad = NW;
+        for (uint32_t w = 0; w < NW; w++) if (sm.pconv[w] == 0u) { first_bad = w; break; }
+        if (first_bad < NW) {
+          uint32_t tru = sm.pexit2[first_bad];  // exact: its entry was exact
+          for (uint32_t w = first_bad + 1; w < NW; w++) {
+            if (w * SEG >= L) break;
+            bool cv;
+            tru = stitch(w, tru, sm.pexit2[w], false, cv);  // pexit2[w]: exit of the chain the first pass left marked there
           }
-          tru = conv ? sm.pexit[w] : curp;
         }
       }
     }
