@@ -570,6 +570,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
       jump[x] = (uint16_t)nx;
     }
     __syncthreads();
+    STAMP(11);
     // The parse chain 0 -> next(0) -> ... is serial, but LZ parses re-synchronise: chains started at
     // different positions usually merge after a few tokens.  So every wavefront walks its own segment
     // speculatively from the segment start (64 positions per step: the window's `next` values sit in one
@@ -587,16 +588,35 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
           const uint32_t x = wb + lane;
           const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
           const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
+          // Pointer doubling inside the window instead of a serial chain: after round r lane j knows the first 2^r
+          // positions of the path that starts at j (a 64-bit mask) and where that path stands (its 2^r-th successor, or
+          // the position at which it left the window).  <= 6 rounds of three lane gathers; the walk itself is then two
+          // v_readlane at the entry.
+          uint32_t hop = nv;
+          uint32_t rlo = lane < 32 ? 1u << lane : 0u, rhi = lane >= 32 ? 1u << (lane - 32) : 0u;
+#pragma nounroll
+          for (int r = 0; r < 6; r++) {
+            const bool inside = hop < wend;
+            if (__ballot(inside) == 0) break;
+            const int src = (int)(inside ? hop - wb : lane);
+            const uint32_t h2 = (uint32_t)__shfl((int)hop, src, 64);
+            const uint32_t l2 = (uint32_t)__shfl((int)rlo, src, 64), g2 = (uint32_t)__shfl((int)rhi, src, 64);
+            rlo |= inside ? l2 : 0u;
+            rhi |= inside ? g2 : 0u;
+            hop = inside ? h2 : hop;
+          }
           uint64_t m = 0;
-          while (curp < wend) {
-            m |= 1ull << (curp - wb);
-            curp = (uint32_t)__builtin_amdgcn_readlane((int)nv, (int)(curp - wb));
+          if (curp < wend) {
+            const int el = (int)(curp - wb);
+            m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, el) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rlo, el);
+            curp = (uint32_t)__builtin_amdgcn_readlane((int)hop, el);
           }
           mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32);  // every lane, same words (no lane-dependent branch at a loop tail)
         }
         sm.pexit[wave] = curp;  // every lane, same value
       }
       __syncthreads();
+      STAMP(12);
       // Stitch segment w from its true entry e: windows wholly before e hold no true position; from e's window on every
       // window is rewritten (a long match may jump over whole windows, whose speculative marks must go too) until the
       // walk meets a speculatively marked position, whose marks are kept from there on.  Returns the segment's true exit.

@@ -27,7 +27,7 @@ lib.hmse_debug_deflate_stamps(buf.ctypes.data, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
 lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
-names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch"]
+names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse: stitch", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
 lens = (cuts[1:] - cuts[:-1])[uniq]
 hb = base >= 0
 Tfull = lens
