@@ -681,17 +681,23 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     // popcounts of contiguous mark words, then every thread walks the set bits of its own words
     {
       uint32_t* const tok = (uint32_t*)(rec + rec_tok_off());
-      const uint32_t nwords = (L + 31) >> 5;
-      const uint32_t wq = (nwords + NT - 1) / NT;
-      const uint32_t w0 = t * wq, w1 = (w0 + wq) < nwords ? (w0 + wq) : nwords;
+      // every thread owns ceil(L / NT) consecutive positions (not whole mark words: with one 32-position word per
+      // thread only L/32 of the NT threads would have work, each with a serial run of ~9 tokens)
+      const uint32_t ppt = (L + NT - 1) / NT;
+      const uint32_t p0 = t * ppt < L ? t * ppt : L, p1 = (p0 + ppt) < L ? (p0 + ppt) : L;
+      auto bits_at = [&](uint32_t pos, uint32_t nb) -> uint32_t {  // nb <= 32 mark bits from position pos on
+        const uint32_t w = pos >> 5;
+        const uint64_t v = (uint64_t)mark[w] | ((uint64_t)mark[w + 1] << 32);
+        return (uint32_t)(v >> (pos & 31u)) & (nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u));
+      };
       uint32_t cntm = 0;
-      for (uint32_t w = w0; w < w1; w++) cntm += (uint32_t)__builtin_popcount(mark[w]);
+      for (uint32_t pos = p0; pos < p1; pos += 32) cntm += (uint32_t)__builtin_popcount(bits_at(pos, p1 - pos));
       uint32_t ntok;
       uint32_t idx = block_exclusive_scan<NT>(cntm, sm.red, &ntok);
-      for (uint32_t w = w0; w < w1; w++) {
-        uint32_t m = mark[w];
+      for (uint32_t pos = p0; pos < p1; pos += 32) {
+        uint32_t m = bits_at(pos, p1 - pos);
         while (m) {
-          const uint32_t x = (w << 5) + (uint32_t)__builtin_ctz(m);
+          const uint32_t x = pos + (uint32_t)__builtin_ctz(m);
           m &= m - 1;
           if (take(x)) {
             const uint32_t l3 = mlen[x], dd = mdist[x];
