@@ -162,3 +162,37 @@ def test_read_path_at_scale(dev):
     res = ingest.ingest_shard(data, IngestConfig())
     back = read.reconstruct_shard(res, verify=True)
     assert torch.equal(back, data)
+
+
+def test_read_path_refuses_inconsistent_inputs(orc, dev):
+    """Out-of-range stream offsets, a DELTA record without a valid base, and a chunk map that disagrees with the stored
+    lengths are reported (per-record flag / HmseError), never dereferenced."""
+    import torch, zlib
+    from hmse_amd import ops
+    c = zlib.compressobj(9, zlib.DEFLATED, -15)
+    s = c.compress(b"hello hello hello hello") + c.flush()
+    streams = torch.from_numpy(np.frombuffer(s * 3, np.uint8).copy()).to(dev)
+    n = len(s)
+    off = torch.tensor([0, n, 2 * n, 3 * n], dtype=torch.int64, device=dev)
+    kind = torch.tensor([0, 2, 2], dtype=torch.uint8, device=dev)
+    raw_len = torch.tensor([23, 23, 23], dtype=torch.int64, device=dev)
+    # record 1: DELTA whose base is itself (not earlier); record 2: DELTA with base -1
+    base = torch.tensor([-1, 1, -1], dtype=torch.int64, device=dev)
+    raw, raw_off, ok = ops.l1_inflate(streams, off, kind, base, raw_len, check=False)
+    assert ok.tolist() == [1, 0, 0] and bytes(raw[:23].tolist()) == b"hello hello hello hello"
+    with pytest.raises(ops.HmseError):
+        ops.l1_inflate(streams, off, kind, base, raw_len)
+    # stream positions beyond the blob (manifest-style starts + lengths)
+    starts = torch.tensor([0, 10 * n, 2 * n], dtype=torch.int64, device=dev)
+    lens = torch.tensor([n, n, 4 * n], dtype=torch.int32, device=dev)
+    _, _, ok = ops.l1_inflate(streams, starts, torch.zeros(3, dtype=torch.uint8, device=dev), None, raw_len, stream_len=lens, check=False)
+    assert ok.tolist() == [1, 0, 0]
+    # chunk map vs stored lengths
+    cuts = torch.tensor([0, 23, 46], dtype=torch.int64, device=dev)
+    good = ops.read_assemble(cuts, torch.tensor([0, 0], dtype=torch.int64, device=dev), raw_off[:2].contiguous(), raw[:23].contiguous())
+    assert bytes(good.tolist()) == b"hello hello hello hello" * 2
+    with pytest.raises(ops.HmseError):
+        ops.read_assemble(cuts, torch.tensor([0, 5], dtype=torch.int64, device=dev), raw_off[:2].contiguous(), raw[:23].contiguous())
+    with pytest.raises(ops.HmseError):
+        ops.read_assemble(torch.tensor([0, 20, 46], dtype=torch.int64, device=dev), torch.tensor([0, 0], dtype=torch.int64, device=dev),
+                          raw_off[:2].contiguous(), raw[:23].contiguous())
