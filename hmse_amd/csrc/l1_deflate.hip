@@ -541,13 +541,19 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
             else { ml = 8; if (maxlen > 8) { fin = false; st = EXTEND; } }
           }
         } else if (st == EXTEND) {
-          uint64_t xa, xb, ya, yb;
+          // 32 bytes per trip, all four reads of each side issued together (one LDS round trip): the dictionary jobs
+          // (near-duplicate chunks) spend most of their trips here, a full-length match is 258 bytes
+          uint64_t xa, xb, ya, yb, za, zb, wa, wb;
           __builtin_memcpy(&xa, W + q + ml, 8); __builtin_memcpy(&xb, W + p + ml, 8);
           __builtin_memcpy(&ya, W + q + ml + 8, 8); __builtin_memcpy(&yb, W + p + ml + 8, 8);
-          const uint64_t x = xa ^ xb, y = ya ^ yb;
+          __builtin_memcpy(&za, W + q + ml + 16, 8); __builtin_memcpy(&zb, W + p + ml + 16, 8);
+          __builtin_memcpy(&wa, W + q + ml + 24, 8); __builtin_memcpy(&wb, W + p + ml + 24, 8);
+          const uint64_t x = xa ^ xb, y = ya ^ yb, z = za ^ zb, w = wa ^ wb;
           if (x) { ml += (uint32_t)__builtin_ctzll(x) >> 3; fin = true; }
           else if (y) { ml += 8 + ((uint32_t)__builtin_ctzll(y) >> 3); fin = true; }
-          else { ml += 16; if (ml >= maxlen) fin = true; }
+          else if (z) { ml += 16 + ((uint32_t)__builtin_ctzll(z) >> 3); fin = true; }
+          else if (w) { ml += 24 + ((uint32_t)__builtin_ctzll(w) >> 3); fin = true; }
+          else { ml += 32; if (ml >= maxlen) fin = true; }
         }
         if (fin) {
           if (ml > maxlen) ml = maxlen;
