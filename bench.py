@@ -199,8 +199,11 @@ def main():
         ul = lens[res.uniq_ids]
         hb = res.base >= 0 if res.base is not None else torch.zeros_like(ul, dtype=torch.bool)
         dl = torch.clamp(ul[res.base.clamp(min=0)], max=32768) if res.base is not None else torch.zeros_like(ul)
-        jobs_T = torch.cat([ul, (ul + dl)[hb]])
-        jobs_L = torch.cat([ul, ul[hb]])
+        # match jobs: one per chunk — its own window, or chunk + dictionary for a chunk with a base (that job emits both the
+        # FULL and the DELTA token list); encode jobs: one per record
+        jobs_T = torch.cat([ul[~hb], (ul + dl)[hb]])
+        jobs_L = torch.cat([ul[~hb], 2 * ul[hb]])
+        enc_L = torch.cat([ul, ul[hb]])
         cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 16000, 5, torch.where(jobs_T <= 21504, 1,
                           torch.where(jobs_T <= 32768, 2, 3)))))
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
@@ -209,9 +212,9 @@ def main():
             # match kernel: window read + token list written (4 B per token, ~ one token per 3.5 positions)
             alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + 1.15 * jobs_L[m].sum().item())
         for slot, lo, hi in ((14, 0, 12288), (15, 12288, 32768)):
-            m = (jobs_L > lo) & (jobs_L <= hi)
+            m = (enc_L > lo) & (enc_L <= hi)
             # encode kernel: token list read, stream written
-            alg[STAGE_NAMES[slot]] = int((1.15 + 1.0 / cf_l1) * jobs_L[m].sum().item())
+            alg[STAGE_NAMES[slot]] = int((1.15 + 1.0 / cf_l1) * enc_L[m].sum().item())
     stage_roof = {}
     for name, k in kern.items():
         if name not in alg:

@@ -395,8 +395,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
     uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
     uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
+    // A dictionary job (variant 1) also yields the chunk's FULL encoding: candidates are walked nearest first and every
+    // chunk position precedes every dictionary position, so the state of the walk when it reaches the first dictionary
+    // candidate IS the result of the FULL walk (same candidates, same depth cut, same filters).  That snapshot goes to a
+    // second pair of arrays (second half of the per-workgroup global scratch) and is parsed and tokenised in a second
+    // pass below: one sort and one walk serve both records, and no separate FULL job runs for a chunk that has a base.
+    uint16_t* const mdistF = (uint16_t*)((uint8_t*)mdist_g + 3 * 32768);
+    uint8_t* const mlenF = (uint8_t*)(mdistF + LCAP);
     if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.rec_off[k] + (variant + 1ull) * rec_size(L) > a.rec_cap) {
-      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
+      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (variant) a.len_full[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small (a dictionary job carries the FULL record too)
       continue;
     }
     const uint8_t* csrc = a.data + cstart;
@@ -419,6 +426,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     if (t < 20) sm.cf[t] = 0;
     if (t == 0) sm.qhead = 0;
     for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
+    if (variant) for (uint32_t i = t; i < L; i += NT) mlenF[i] = 0;
     __syncthreads();
 
     STAMP(0);
@@ -519,6 +527,11 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
           q = qn;
           uint32_t kb = kn;
           if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }  // prefetch the next candidate
+          // first dictionary candidate of this position: what the walk holds now is the FULL result (bit 31 of bd = done)
+          if (variant && q < Dl && !(bd >> 31)) {
+            if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
+            bd |= 0x80000000u;
+          }
           // a candidate the byte-4 filter rejects (37 % of them on text) is consumed on the spot and the next one takes
           // its place in this trip: the filter needs nothing but the two prefetched values
           // (classes with the filter array only: where byte 4 is a dependent window read the second test costs more than it saves)
@@ -526,6 +539,10 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
             kk++;
             q = qn; kb = kn;
             if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }
+            if (variant && q < Dl && !(bd >> 31)) {
+              if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
+              bd |= 0x80000000u;
+            }
           }
           fin = true; ml = 0;
           if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
@@ -559,13 +576,16 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
           if (ml > maxlen) ml = maxlen;
           bool pos_done = false;
           if (ml > best) {
-            best = ml; bd = p - q;
+            best = ml; bd = (bd & 0x80000000u) | (p - q);
             if (ml == maxlen) pos_done = true; else probe = ld32(W + p + best - 3);
           }
           if (++kk > kmax) pos_done = true;
           st = PROBE;
           if (pos_done) {
-            if (best >= MINM) { mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd; }
+            if (best >= MINM) {
+              mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd;
+              if (variant && !(bd >> 31)) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }  // never reached the dictionary
+            }
             st = FETCH;
           }
         }
@@ -573,14 +593,25 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     }
     __syncthreads();
     STAMP(3);
+    // pass 0: this job's own record (DELTA for a dictionary job); pass 1 (dictionary jobs only): the FULL record
+    for (uint32_t pass = 0; pass < (variant ? 2u : 1u); pass++) {
+    const uint8_t* const mlen_c = pass ? mlenF : mlen;
+    const uint16_t* const mdist_c = pass ? mdistF : mdist;
+    uint8_t* const rec_c = pass ? a.recs + a.rec_off[k] : rec;
+    if (pass) {
+      __syncthreads();  // histograms of pass 0 have been copied out
+      for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
+      if (t < 32) sm.df[t] = 0;
+      __syncthreads();
+    }
     // ---- phase 6: parse by pointer doubling -------------------------------------------------------
     auto take = [&](uint32_t x) -> bool {
-      const uint32_t ml = mlen[x];
-      return ml != 0 && !(x + 1 < L && mlen[x + 1] > ml);
+      const uint32_t ml = mlen_c[x];
+      return ml != 0 && !(x + 1 < L && mlen_c[x + 1] > ml);
     };
     for (uint32_t x = t; x <= L; x += NT) {
       uint32_t nx = L;
-      if (x < L) { nx = x + (take(x) ? (uint32_t)mlen[x] + 3u : 1u); if (nx > L) nx = L; }
+      if (x < L) { nx = x + (take(x) ? (uint32_t)mlen_c[x] + 3u : 1u); if (nx > L) nx = L; }
       jump[x] = (uint16_t)nx;
     }
     __syncthreads();
@@ -694,7 +725,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     // token index of a marked position = number of marked positions before it: workgroup prefix scan over the
     // popcounts of contiguous mark words, then every thread walks the set bits of its own words
     {
-      uint32_t* const tok = (uint32_t*)(rec + rec_tok_off());
+      uint32_t* const tok = (uint32_t*)(rec_c + rec_tok_off());
       // every thread owns ceil(L / NT) consecutive positions (not whole mark words: with one 32-position word per
       // thread only L/32 of the NT threads would have work, each with a serial run of ~9 tokens)
       const uint32_t ppt = (L + NT - 1) / NT;
@@ -714,7 +745,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
           const uint32_t x = pos + (uint32_t)__builtin_ctz(m);
           m &= m - 1;
           if (take(x)) {
-            const uint32_t l3 = mlen[x], dd = mdist[x];
+            const uint32_t l3 = mlen_c[x], dd = mdist_c[x];
             uint32_t code, eb, ev;
             len_sym(l3 + 3u, code, eb, ev); atomicAdd(&sm.lf[code], 1u);
             dist_sym(dd, code, eb, ev); atomicAdd(&sm.df[code], 1u);
@@ -727,13 +758,14 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
           idx++;
         }
       }
-      if (t == 0) { atomicAdd(&sm.lf[256], 1u); *(uint32_t*)(rec + rec_ntok_off()) = ntok; }
+      if (t == 0) { atomicAdd(&sm.lf[256], 1u); *(uint32_t*)(rec_c + rec_ntok_off()) = ntok; }
       __syncthreads();
       STAMP(5);
-      uint32_t* const r_hist = (uint32_t*)rec;
+      uint32_t* const r_hist = (uint32_t*)rec_c;
       for (uint32_t i = t; i < 288; i += NT) r_hist[i] = sm.lf[i];
       if (t < 32) r_hist[288 + t] = sm.df[t];
     }
+    }  // pass
     STAMP(9);
   }
 #ifdef HMSE_DFL_STAMPS
@@ -1004,7 +1036,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
            : T <= (uint64_t)TCAP_SG3 ? 2u : 3u;
   };
   const bool enc_ok = in && L <= 32768;
-  append(in, cls(L), (uint32_t)(k << 1));
+  append(in && !hasb, cls(L), (uint32_t)(k << 1));  // a chunk with a base gets its FULL record from the dictionary job
   append(in && hasb, cls(L + Dl), (uint32_t)((k << 1) | 1u));
   append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1));
   append(enc_ok && hasb, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | 1u));
@@ -1143,7 +1175,7 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.list_stride = 2 * n_sel;
   r.lists = w.take<uint32_t>(N_LIST * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
-  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(3 * 32768, 256));
+  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(6 * 32768, 256));
   r.fixed_bytes = w.off;
   r.recs = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
@@ -1211,7 +1243,7 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
   a.rec_off = w.rec_off; a.recs = w.recs; a.len_full = w.len_full; a.len_delta = w.len_delta;
   a.rec_cap = avail; a.status = status;
   a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
-  a.scratch2 = w.scratch2; a.scratch2_stride = hmse_align_up(3 * 32768, 256);
+  a.scratch2 = w.scratch2; a.scratch2_stride = hmse_align_up(6 * 32768, 256);
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;
   // big windows first (few, long jobs), then the LDS classes
