@@ -595,7 +595,24 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     STAMP(3);
     // pass 0: this job's own record (DELTA for a dictionary job); pass 1 (dictionary jobs only): the FULL record
     for (uint32_t pass = 0; pass < (variant ? 2u : 1u); pass++) {
-    const uint8_t* const mlen_c = pass ? mlenF : mlen;
+    const uint8_t* mlen_c = pass ? mlenF : mlen;
+    // Match lengths that live in HBM (the FULL snapshot of a dictionary job; every length array of the classes that keep
+    // them out of LDS) are staged into a free LDS region first: the parse reads each of them three times.
+    {
+      uint8_t* stage = nullptr;
+      if constexpr (!LDSM) stage = smem + LY::A_OFF;                                   // unused by this kernel in class B
+      else if constexpr (!MLG) { if (pass) stage = smem + LY::ML_OFF; }                // the DELTA lengths are dead by now
+      else {
+        const uint32_t joff = (2u * (L + 1u) + 15u) & ~15u;                            // behind the next-pointers
+        if (joff + L + 16u <= (uint32_t)LY::A_SZ) stage = smem + LY::A_OFF + joff;
+      }
+      if (stage) {
+        __syncthreads();
+        for (uint32_t i = t * 16; i < L; i += NT * 16) { const uint4 v = *(const uint4*)(mlen_c + i); *(uint4*)(stage + i) = v; }
+        mlen_c = stage;
+        __syncthreads();
+      }
+    }
     const uint16_t* const mdist_c = pass ? mdistF : mdist;
     uint8_t* const rec_c = pass ? a.recs + a.rec_off[k] : rec;
     if (pass) {
