@@ -154,21 +154,28 @@ __device__ void huff_lengths_wave(const uint32_t* freq, uint32_t n, uint32_t lim
   }
   if (lane < 32) hs->cnt[lane] = 0;
   wave_sync();
-  // (4) two-queue merge (leaf wins ties), serial on lane 0
+  // (4) two-queue merge (leaf wins ties), serial on lane 0.  The heads of the two queues stay in registers: one LDS
+  // read per pick (the new head) instead of re-reading both heads and both picked weights — this loop is the longest
+  // serial stretch of the encode kernel
   if (lane == 0) {
+    constexpr uint32_t INF = 0xFFFFFFFFu;
     uint32_t li = 0, ii = m, ni = m;
+    uint32_t wl = m ? hs->w[0] : INF, wi = INF;  // weight at the head of the leaf queue / the internal-node queue
     for (uint32_t step = 0; step + 1 < m; step++) {
-      uint32_t pick0, pick1;
+      uint32_t pick0, pick1, v0, v1;
       {
-        bool tl = (li < m && ii < ni) ? (hs->w[li] <= hs->w[ii]) : (li < m);
-        pick0 = tl ? li++ : ii++;
+        const bool tl = li < m && (ii >= ni || wl <= wi);
+        if (tl) { pick0 = li++; v0 = wl; wl = li < m ? hs->w[li] : INF; }
+        else { pick0 = ii++; v0 = wi; wi = ii < ni ? hs->w[ii] : INF; }
       }
       {
-        bool tl = (li < m && ii < ni) ? (hs->w[li] <= hs->w[ii]) : (li < m);
-        pick1 = tl ? li++ : ii++;
+        const bool tl = li < m && (ii >= ni || wl <= wi);
+        if (tl) { pick1 = li++; v1 = wl; wl = li < m ? hs->w[li] : INF; }
+        else { pick1 = ii++; v1 = wi; wi = ii < ni ? hs->w[ii] : INF; }
       }
-      hs->w[ni] = hs->w[pick0] + hs->w[pick1];
+      hs->w[ni] = v0 + v1;
       hs->parent[pick0] = (uint16_t)ni; hs->parent[pick1] = (uint16_t)ni;
+      if (ii == ni) wi = v0 + v1;  // the internal queue was empty: the new node is its head
       ni++;
     }
   }
