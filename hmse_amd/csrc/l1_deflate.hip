@@ -501,6 +501,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
       for (;;) {
+#ifdef HMSE_DFL_STAMPS
+        if (t == 0) stamp_acc[13]++;  // trips of wavefront 0 through the state machine
+#endif
         const uint64_t need = __ballot(st == FETCH);
         if (need) {  // wave-aggregated pull of the next sorted ranks
           const uint32_t leader = (uint32_t)__builtin_ctzll(need);
@@ -791,9 +794,12 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
     }
     }  // pass
     STAMP(9);
+#ifdef HMSE_DFL_STAMPS
+    if (t == 0) { stamp_acc[14] += L; stamp_acc[15]++; }
+#endif
   }
 #ifdef HMSE_DFL_STAMPS
-  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[LDSM ? (TCAP <= 9216 ? 0 : 1) : 2][i], stamp_acc[i]);
+  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2][i], stamp_acc[i]);
 #endif
 }
 

@@ -40,11 +40,14 @@ for ci_, nm in enumerate(("S", "S2", "SG", "SG2", "SG3", "B")):
     m_ = cls_ == ci_
     print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
-for c, cn in enumerate(["classes with T <= 9216 (S)", "the other LDS classes (S2, SG, SG2, SG3)", "big (B)"]):
+for c, cn in enumerate(["class S (T <= 9216)", "classes S2, SG (T <= 16000)", "classes SG2, SG3, B (dictionary jobs and big chunks)"]):
     row = buf[c * 16:(c + 1) * 16].astype(np.float64)
+    trips, positions, jobs = row[13], row[14], row[15]
+    row[13:] = 0
     tot = row.sum()
     if tot == 0:
         continue
+    print(cn, "jobs %d  chunk positions %.1f M  trips of wavefront 0 through the matcher: %.1f per job = %.2f per 64 positions" % (jobs, positions / 1e6, trips / max(jobs, 1), 64 * trips / max(positions, 1)))
     print(cn, "total Mclk %.1f" % (tot / 1e6))
     for i, nm in enumerate(names):
         print("   %-18s %6.2f %%" % (nm, 100 * row[i] / tot))
