@@ -266,8 +266,10 @@ def main():
             "metric": "ingest_GiB_per_s", "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u8", "data": f"synthetic: {source}" if source.startswith("wiki") else source,
-            "config": {"workload": f"{a.layers} L1-L4 ingest (FastCDC 2/8/32 KiB + SHA-256 dedupe + MinHash-128/LSH 4x32 + "
-                                   f"dictionary DEFLATE level-9 profile) over {tot['bytes'] / 1e9:.2f} GB {a.corpus}",
+            "config": {"workload": f"{a.layers} ingest (" + " + ".join(nm for bit, nm in (
+                           (2, "FastCDC 2/8/32 KiB"), (4, "SHA-256 dedupe"), (8, "MinHash-128/LSH 4x32"),
+                           (1, "dictionary DEFLATE level-9 profile" if cfg.layers & 8 else "DEFLATE level-9 profile")) if cfg.layers & bit)
+                                   + f") over {tot['bytes'] / 1e9:.2f} GB {a.corpus}",
                        "total_bytes": tot["bytes"], "seg_size": seg, "sharding": f"{world} x contiguous 4 MiB-segment runs",
                        "collective": "all_gather(digests) over RCCL" if distributed else "none"},
             "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4), "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4),

@@ -19,6 +19,8 @@ ABLATIONS = {
     "l1_cdc_dedupe": LAYER_L1 | LAYER_L2 | LAYER_L3,
     "full": LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4,
     "l4_only": LAYER_L2 | LAYER_L4,
+    # not in the reference's matrix: BASELINE.json configs[1] (FastCDC + SHA-256 dedup only, no codec)
+    "cdc_dedupe": LAYER_L2 | LAYER_L3,
 }
 
 

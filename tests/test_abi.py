@@ -54,7 +54,7 @@ def test_reference_preset_and_ablations():
     p = IngestConfig.reference_preset()                      # README.md:2444-2446
     assert (p.min_size, p.avg_size, p.max_size) == (1024, 4096, 16384)
     assert _lib.hip_lib().hmse_cfg_validate(C.byref(p.to_c())) == 0
-    assert set(ABLATIONS) == {"l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only"}  # VALIDATION_METHODS.md:458-464
+    assert set(ABLATIONS) == {"l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only", "cdc_dedupe"}  # VALIDATION_METHODS.md:458-464 + BASELINE configs[1]
     assert ABLATIONS["full"] == 15
 
 

@@ -63,7 +63,7 @@ def test_full_pipeline_equals_oracle_and_reconstructs(orc, dev):
     assert manifest.reconstruct(manifest.Manifest.from_bytes(m.to_bytes())) == data.tobytes()   # 100 % lossless (VALIDATION_METHODS.md:257)
 
 
-@pytest.mark.parametrize("preset", ["l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only"])
+@pytest.mark.parametrize("preset", ["l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only", "cdc_dedupe"])
 def test_ablation_matrix_runs_and_is_lossless(preset, dev):
     """VALIDATION_METHODS.md:458-464: every layer subset produces a decodable result."""
     import torch
@@ -81,7 +81,7 @@ def test_ablation_matrix_runs_and_is_lossless(preset, dev):
             d = zlib.decompressobj(-15, zdict=zd) if zd else zlib.decompressobj(-15)
             assert d.decompress(out[off[k]:off[k + 1]].tobytes()) == data[cuts[uniq[k]]:cuts[uniq[k] + 1]].tobytes()
     else:
-        assert preset == "l4_only" and res.sig is not None
+        assert (preset == "l4_only" and res.sig is not None) or (preset == "cdc_dedupe" and res.digests is not None and res.sig is None)
 
 
 def test_two_shard_run_equals_oracle_with_two_shards(orc, dev):
