@@ -13,7 +13,7 @@ mib = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 prof = sys.argv[2] if len(sys.argv) > 2 else "wikipedia"
 O.build()
 cfg = IngestConfig()
-data, src = corpus.load(prof, mib << 20, seed=42)
+data, src = (corpus.random_bytes(mib << 20), "PRNG bytes (seed 0xDEADBEEF, VALIDATION_METHODS.md:213)") if prof == "random" else corpus.load(prof, mib << 20, seed=42)
 t0 = time.time()
 res = ingest.ingest_shard(torch.from_numpy(data).to("cuda:0"), cfg)
 torch.cuda.synchronize()
