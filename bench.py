@@ -29,6 +29,9 @@ STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel
                10: "l1_deflate_kernel<1024,32768,32768,true,true,true,true>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false,false>",
                12: "l1_deflate_kernel<1024,12288,12288,true,true,false,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true,false>",
                14: "l1_encode_kernel<256,0,12288>", 15: "l1_encode_kernel<256,12288,32768>"}
+# what the SQ counters say about the kernels that can be "dominant" (profiles/r1/h_pmc_sq_counters_2GB.csv)
+VALU_NOTE = {"l4_minhash_kernel": "; SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 8 waves per SIMD = 1.1, i.e. the vector ALUs are "
+                                  "saturated (9.25 instructions per (distinct shingle, seed) pair)"}
 # match-kernel size classes S, SG2, SG3, B, S2, SG (hmse_amd/csrc/l1_deflate.hip) -> profile slot
 DEFLATE_CLASS_SLOT = {0: 8, 1: 9, 2: 10, 3: 11, 4: 12, 5: 13}
 
@@ -282,7 +285,7 @@ def main():
             r = stage_roof[dom]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": r["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": r["frac_hbm"], "traffic": measured_traffic(dom, tot["bytes"], world),
-                               "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0"}
+                               "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0" + VALU_NOTE.get(dom, "")}
         out["stage_roofline"] = stage_roof
         if read_info:
             out["read_path"] = read_info
