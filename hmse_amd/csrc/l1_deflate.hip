@@ -97,7 +97,7 @@ template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = f
 struct Layout {
   static constexpr int LCAP = LCAP_;
   static constexpr int W_OFF = 0;
-  static constexpr int W_SZ = align16(TCAP + 32);
+  static constexpr int W_SZ = align16(TCAP + 64);
   static constexpr int CUR_OFF = W_OFF + W_SZ;          // packed u16[NBK] bucket cursors; later the Huffman scratch
   static constexpr int CUR_SZ = NBK * 2;               // two 16-bit cursors per dword
   static constexpr int MARK_OFF = CUR_OFF + CUR_SZ;
@@ -354,7 +354,7 @@ struct Scratch {
 };
 
 template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
-__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
+__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <= 16000 || NOK) ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
   using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG, NOK>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
       if (i + 16 <= L) { const uint4 v = load_u4_unaligned(csrc + i); __builtin_memcpy(W + Dl + i, &v, 16); }
       else for (uint32_t b = i; b < L; b++) W[Dl + b] = csrc[b];
     }
-    if (t < 32) W[T + t] = 0;
+    if (t < 64) W[T + t] = 0;
     for (uint32_t i = t; i < NBK / 2; i += NT) cur[i] = 0;
     for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;
     for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
@@ -568,19 +568,33 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && (TCAP <= 16000 || NOK) ?
             else { ml = 8; if (maxlen > 8) { fin = false; st = EXTEND; } }
           }
         } else if (st == EXTEND) {
-          // 32 bytes per trip, all four reads of each side issued together (one LDS round trip): the dictionary jobs
+          // 32 bytes per trip, all reads of each side issued together (one LDS round trip): the dictionary jobs
           // (near-duplicate chunks) spend most of their trips here, a full-length match is 258 bytes
-          uint64_t xa, xb, ya, yb, za, zb, wa, wb;
-          __builtin_memcpy(&xa, W + q + ml, 8); __builtin_memcpy(&xb, W + p + ml, 8);
-          __builtin_memcpy(&ya, W + q + ml + 8, 8); __builtin_memcpy(&yb, W + p + ml + 8, 8);
-          __builtin_memcpy(&za, W + q + ml + 16, 8); __builtin_memcpy(&zb, W + p + ml + 16, 8);
-          __builtin_memcpy(&wa, W + q + ml + 24, 8); __builtin_memcpy(&wb, W + p + ml + 24, 8);
-          const uint64_t x = xa ^ xb, y = ya ^ yb, z = za ^ zb, w = wa ^ wb;
-          if (x) { ml += (uint32_t)__builtin_ctzll(x) >> 3; fin = true; }
-          else if (y) { ml += 8 + ((uint32_t)__builtin_ctzll(y) >> 3); fin = true; }
-          else if (z) { ml += 16 + ((uint32_t)__builtin_ctzll(z) >> 3); fin = true; }
-          else if (w) { ml += 24 + ((uint32_t)__builtin_ctzll(w) >> 3); fin = true; }
-          else { ml += 32; if (ml >= maxlen) fin = true; }
+          // (64 bytes where the class runs one workgroup per CU and so may use 128 VGPRs: SG3 and B, the classes of the
+          // largest dictionary jobs)
+          if constexpr (!LDSM || TCAP > 21504) {
+            uint64_t da[8], db[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { __builtin_memcpy(&da[u], W + q + ml + 8 * u, 8); __builtin_memcpy(&db[u], W + p + ml + 8 * u, 8); }
+            uint32_t adv = 64;
+            bool hit = false;
+#pragma unroll
+            for (int u = 7; u >= 0; u--) { const uint64_t x = da[u] ^ db[u]; if (x) { adv = 8 * u + ((uint32_t)__builtin_ctzll(x) >> 3); hit = true; } }
+            ml += adv;
+            if (hit || ml >= maxlen) fin = true;
+          } else {
+            uint64_t xa, xb, ya, yb, za, zb, wa, wb;
+            __builtin_memcpy(&xa, W + q + ml, 8); __builtin_memcpy(&xb, W + p + ml, 8);
+            __builtin_memcpy(&ya, W + q + ml + 8, 8); __builtin_memcpy(&yb, W + p + ml + 8, 8);
+            __builtin_memcpy(&za, W + q + ml + 16, 8); __builtin_memcpy(&zb, W + p + ml + 16, 8);
+            __builtin_memcpy(&wa, W + q + ml + 24, 8); __builtin_memcpy(&wb, W + p + ml + 24, 8);
+            const uint64_t x = xa ^ xb, y = ya ^ yb, z = za ^ zb, w = wa ^ wb;
+            if (x) { ml += (uint32_t)__builtin_ctzll(x) >> 3; fin = true; }
+            else if (y) { ml += 8 + ((uint32_t)__builtin_ctzll(y) >> 3); fin = true; }
+            else if (z) { ml += 16 + ((uint32_t)__builtin_ctzll(z) >> 3); fin = true; }
+            else if (w) { ml += 24 + ((uint32_t)__builtin_ctzll(w) >> 3); fin = true; }
+            else { ml += 32; if (ml >= maxlen) fin = true; }
+          }
         }
         if (fin) {
           if (ml > maxlen) ml = maxlen;
