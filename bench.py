@@ -24,11 +24,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+_CLS = {8: "1024,9216,9216,true,false,false,false", 9: "1024,21504,21504,true,true,true,true", 10: "1024,32768,32768,true,true,true,true",
+        11: "512,65536,32768,false,false,false,false", 12: "1024,12288,12288,true,true,false,false", 13: "1024,16000,16000,true,true,true,false"}
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
-               8: "l1_deflate_kernel<1024,9216,9216,true,false,false,false>", 9: "l1_deflate_kernel<1024,21504,21504,true,true,true,true>",
-               10: "l1_deflate_kernel<1024,32768,32768,true,true,true,true>", 11: "l1_deflate_kernel<512,65536,32768,false,false,false,false>",
-               12: "l1_deflate_kernel<1024,12288,12288,true,true,false,false>", 13: "l1_deflate_kernel<1024,16000,16000,true,true,true,false>",
                14: "l1_encode_kernel<256,0,12288>", 15: "l1_encode_kernel<256,12288,32768>"}
+# match kernels: slots 8..13 = plain jobs of a size class, 18..23 = its dictionary jobs (last template argument)
+STAGE_NAMES.update({slot: f"l1_deflate_kernel<{args},false>" for slot, args in _CLS.items()})
+STAGE_NAMES.update({slot + 10: f"l1_deflate_kernel<{args},true>" for slot, args in _CLS.items()})
 # what the SQ counters say about the kernels that can be "dominant" (profiles/r1/h_pmc_sq_counters_2GB.csv)
 VALU_NOTE = {"l4_minhash_kernel": "; SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 8 waves per SIMD = 1.1, i.e. the vector ALUs are "
                                   "saturated (9.25 instructions per (distinct shingle, seed) pair)"}
@@ -204,16 +206,18 @@ def main():
         dl = torch.clamp(ul[res.base.clamp(min=0)], max=32768) if res.base is not None else torch.zeros_like(ul)
         # match jobs: one per chunk — its own window, or chunk + dictionary for a chunk with a base (that job emits both the
         # FULL and the DELTA token list); encode jobs: one per record
-        jobs_T = torch.cat([ul[~hb], (ul + dl)[hb]])
-        jobs_L = torch.cat([ul[~hb], 2 * ul[hb]])
         enc_L = torch.cat([ul, ul[hb]])
-        cls = torch.where(jobs_T <= 9216, 0, torch.where(jobs_T <= 12288, 4, torch.where(jobs_T <= 16000, 5, torch.where(jobs_T <= 21504, 1,
-                          torch.where(jobs_T <= 32768, 2, 3)))))
         cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
-        for c, slot in DEFLATE_CLASS_SLOT.items():
-            m = cls == c
-            # match kernel: window read + token list written (4 B per token, ~ one token per 3.5 positions)
-            alg[STAGE_NAMES[slot]] = int(jobs_T[m].sum().item() + 1.15 * jobs_L[m].sum().item())
+
+        def by_class(T, Ltok, off):
+            cls = torch.where(T <= 9216, 0, torch.where(T <= 12288, 4, torch.where(T <= 16000, 5, torch.where(T <= 21504, 1, torch.where(T <= 32768, 2, 3)))))
+            for c, slot in DEFLATE_CLASS_SLOT.items():
+                m = cls == c
+                # match kernel: window read + token list(s) written (4 B per token, ~ one token per 3.5 positions)
+                alg[STAGE_NAMES[slot + off]] = int(T[m].sum().item() + 1.15 * Ltok[m].sum().item())
+
+        by_class(ul[~hb], ul[~hb], 0)                # plain jobs
+        by_class((ul + dl)[hb], 2 * ul[hb], 10)      # dictionary jobs: two token lists
         for slot, lo, hi in ((14, 0, 12288), (15, 12288, 32768)):
             m = (enc_L > lo) & (enc_L <= hi)
             # encode kernel: token list read, stream written

@@ -353,7 +353,9 @@ struct Scratch {
   uint16_t jumpA[32768 + 8];
 };
 
-template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
+// DICT: the instantiation that runs the dictionary jobs of its class (chunk + base chunk; yields the DELTA and the FULL
+// record).  Plain jobs run the DICT = false instantiation, which carries none of the snapshot code or its registers.
+template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false, bool DICT = false>
 __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <= 16000 || NOK) ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
   using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG, NOK>;
   constexpr int LCAP = LY::LCAP;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     STAMP(10);
     const uint32_t job = a.jobs[ji];
     const uint64_t k = job >> 1;
-    const uint32_t variant = job & 1u;
+    constexpr uint32_t variant = DICT ? 1u : 0u;  // (== job & 1: the lists are split by variant)
     const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
     const uint64_t cstart = a.cuts[c];
     const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
@@ -1039,7 +1041,9 @@ __global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
 constexpr int NT_M = 1024, TCAP_SG3 = 32768;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_LIST = 9;       // + two encode-kernel lists (by chunk length): lists 6 and 7; class SG2 is list 8
+constexpr int N_LIST = 15;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); encode-kernel lists by
+                                // chunk length: 6 and 7; dictionary jobs per class: lists 9..14 (dict_list)
+__host__ __device__ constexpr uint32_t dict_list(uint32_t c) { return c == 0 ? 9u : c == 4 ? 10u : c == 5 ? 11u : c == 8 ? 12u : c == 2 ? 13u : 14u; }
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
@@ -1081,7 +1085,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   };
   const bool enc_ok = in && L <= 32768;
   append(in && !hasb, cls(L), (uint32_t)(k << 1));  // a chunk with a base gets its FULL record from the dictionary job
-  append(in && hasb, cls(L + Dl), (uint32_t)((k << 1) | 1u));
+  append(in && hasb, dict_list(cls(L + Dl)), (uint32_t)((k << 1) | 1u));
   append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1));
   append(enc_ok && hasb, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | 1u));
 }
@@ -1225,16 +1229,16 @@ static Ws carve(void* ws, uint64_t n_sel) {
   return r;
 }
 
-template <int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
+template <bool DICT, int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
   using LY = Layout<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK, DICT>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
       return HMSE_EHIP;
     attr_set = true;
   }
-  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
+  l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK, DICT><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -1289,33 +1293,26 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
   a.scratch = w.scratch; a.scratch_stride = hmse_align_up(sizeof(Scratch), 256);
   a.scratch2 = w.scratch2; a.scratch2_stride = hmse_align_up(6 * 32768, 256);
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
-  const uint64_t max_jobs = 2 * n_sel;
+  const uint64_t max_jobs = 2 * n_sel;  // (upper bound of any list)
   // big windows first (few, long jobs), then the LDS classes
   auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 16 + c; };
-  sel(3);
-  PROF_BEGIN(8 + 3, stream);
-  if (launch_class<NT_B, TCAP_B, LCAP_B, false>(a, (uint32_t)(max_jobs < (uint64_t)N_WG_B ? max_jobs : (uint64_t)N_WG_B), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 3, stream);
-  sel(2);
-  PROF_BEGIN(8 + 2, stream);
-  if (launch_class<NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true>(a, (uint32_t)(max_jobs < 256 ? max_jobs : 256), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 2, stream);
-  sel(8);
-  PROF_BEGIN(8 + 1, stream);
-  if (launch_class<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 1, stream);
-  sel(5);
-  PROF_BEGIN(8 + 5, stream);
-  if (launch_class<NT_S, TCAP_SG, TCAP_SG, true, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 5, stream);
-  sel(4);
-  PROF_BEGIN(8 + 4, stream);
-  if (launch_class<NT_S, TCAP_S2, TCAP_S2, true, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 4, stream);
-  sel(0);
-  PROF_BEGIN(8 + 0, stream);
-  if (launch_class<NT_S, TCAP_S, TCAP_S, true>(a, (uint32_t)(max_jobs < 512 ? max_jobs : 512), stream) != HMSE_OK) return HMSE_EHIP;
-  PROF_END(8 + 0, stream);
+  // per class: the plain jobs, then the dictionary jobs (profile slots 8..13 and 18..23)
+#define HMSE_DFL_LAUNCH(LIST, SLOT, GRID, ...)                                                                      \
+  sel(LIST);                                                                                                         \
+  PROF_BEGIN(SLOT, stream);                                                                                          \
+  if (launch_class<false, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
+  PROF_END(SLOT, stream);                                                                                            \
+  sel((int)dict_list(LIST));                                                                                         \
+  PROF_BEGIN((SLOT) + 10, stream);                                                                                   \
+  if (launch_class<true, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
+  PROF_END((SLOT) + 10, stream);
+  HMSE_DFL_LAUNCH(3, 8 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
+  HMSE_DFL_LAUNCH(2, 8 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
+  HMSE_DFL_LAUNCH(8, 8 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
+  HMSE_DFL_LAUNCH(5, 8 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
+  HMSE_DFL_LAUNCH(4, 8 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
+  HMSE_DFL_LAUNCH(0, 8 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
+#undef HMSE_DFL_LAUNCH
   // encode kernel: one 256-thread workgroup per job, two instantiations by chunk length (LDS image size)
   {
     using E1 = EncLayout<256, 0, 12288>;
