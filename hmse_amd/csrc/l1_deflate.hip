@@ -835,7 +835,7 @@ struct EncLayout {
 };
 
 template <int NT, int LMIN, int LCAP>
-__global__ __launch_bounds__(NT, 6) void l1_encode_kernel(Args a) {
+__global__ __launch_bounds__(NT, 7) void l1_encode_kernel(Args a) {
   using EL = EncLayout<NT, LMIN, LCAP>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Small<NT>& sm = *(Small<NT>*)(smem + EL::SMALL_OFF);
@@ -1325,7 +1325,7 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
     }
     sel(6);
     PROF_BEGIN(14, stream);
-    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 1536 ? max_jobs : 1536)), dim3(256), E1::TOTAL, stream>>>(a);
+    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 1792 ? max_jobs : 1792)), dim3(256), E1::TOTAL, stream>>>(a);
     PROF_END(14, stream);
     sel(7);
     PROF_BEGIN(15, stream);
