@@ -829,13 +829,13 @@ struct EncLayout {
   static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT>));
   static constexpr int HS_OFF = SMALL_OFF + SMALL_SZ;
   static constexpr int HS_SZ = align16((int)(sizeof(HuffL) + sizeof(HuffD)));
-  static constexpr int OUT_OFF = HS_OFF + HS_SZ;
+  static constexpr int OUT_OFF = HS_OFF;                // the bit image reuses the Huffman scratch (dead once the codes exist)
   static constexpr int OUT_SZ = align16(LCAP + 80);
-  static constexpr int TOTAL = OUT_OFF + OUT_SZ;
+  static constexpr int TOTAL = OUT_OFF + (OUT_SZ > HS_SZ ? OUT_SZ : HS_SZ);
 };
 
 template <int NT, int LMIN, int LCAP>
-__global__ __launch_bounds__(NT, 7) void l1_encode_kernel(Args a) {
+__global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   using EL = EncLayout<NT, LMIN, LCAP>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Small<NT>& sm = *(Small<NT>*)(smem + EL::SMALL_OFF);
@@ -868,7 +868,6 @@ __global__ __launch_bounds__(NT, 7) void l1_encode_kernel(Args a) {
   for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = r_hist[i];
   if (t < 32) sm.df[t] = r_hist[288 + t];
   if (t < 20) sm.cf[t] = 0;
-  for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;
   __syncthreads();
   // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
   if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
@@ -945,6 +944,8 @@ __global__ __launch_bounds__(NT, 7) void l1_encode_kernel(Args a) {
   if (wave == 0) huff_codes_wave(sm.ll, mode == 1 ? 288 : 286, sm.lc, hsL->cnt);
   if (wave == 1) huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
   if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
+  __syncthreads();
+  for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;  // (the image shares LDS with the scratch used above)
   __syncthreads();
   // ---- phase 11: emit ----------------------------------------------------------------------------------------
   if (wave == 0) {
@@ -1325,11 +1326,11 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
     }
     sel(6);
     PROF_BEGIN(14, stream);
-    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 1792 ? max_jobs : 1792)), dim3(256), E1::TOTAL, stream>>>(a);
+    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);
     PROF_END(14, stream);
     sel(7);
     PROF_BEGIN(15, stream);
-    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 768 ? max_jobs : 768)), dim3(256), E2::TOTAL, stream>>>(a);
+    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), E2::TOTAL, stream>>>(a);
     PROF_END(15, stream);
     HMSE_LAUNCH_CHECK();
   }
