@@ -145,7 +145,7 @@ __device__ __forceinline__ uint32_t decode_sym(Bits& br, const LaneCode& lc, con
   return uni(sym[idx]);
 }
 
-__global__ __launch_bounds__(NT) void l1_inflate_kernel(Args a) {
+__global__ __launch_bounds__(NT, 8) void l1_inflate_kernel(Args a) {
   __shared__ WaveTables s_tab[NT / 64];
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   WaveTables& T = s_tab[wave];
