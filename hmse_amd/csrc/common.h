@@ -35,6 +35,10 @@ struct WsCarver {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+// number of set bits of m below this lane (v_mbcnt: no lane-mask registers)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 __device__ __forceinline__ uint4 load_u4_unaligned(const uint8_t* p) {
   uint4 v;

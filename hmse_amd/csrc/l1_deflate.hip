@@ -31,6 +31,32 @@ constexpr uint32_t MINM = 4, MAXM = 258, WMAX = 32768;
 __device__ __forceinline__ uint32_t hash4(uint32_t x) { return (x * 0x9E3779B1u) >> (32 - HB); }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+// Window bytes at an ARBITRARY byte offset, fetched with naturally aligned dword reads and shifted into place in registers
+// (v_alignbyte_b32).  Measured on gfx950 (tools/ubench/lds_unaligned.hip, profiles/r2/lds_unaligned_gfx950.txt): an LDS read
+// whose per-lane addresses are off the instruction's natural alignment — ds_read_b32 included — costs ~64 LDS clocks per
+// wave-instruction (one per lane) against 6.7 for an aligned random ds_read_b32; the matcher compares window bytes at
+// arbitrary offsets all the time, so every such read goes through these helpers.  `W` is 16-byte aligned.
+__device__ __forceinline__ uint32_t alignb(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ uint32_t ld32a(const uint8_t* W, uint32_t off) {
+  const uint32_t* w = (const uint32_t*)(W + (off & ~3u));
+  return alignb(w[1], w[0], off);
+}
+__device__ __forceinline__ void ld64a(const uint8_t* W, uint32_t off, uint32_t& x0, uint32_t& x1) {
+  const uint32_t* w = (const uint32_t*)(W + (off & ~3u));
+  const uint32_t a = w[0], b = w[1], c = w[2];
+  x0 = alignb(b, a, off); x1 = alignb(c, b, off);
+}
+// N * 8 bytes at W + off as 64-bit pieces
+template <int N>
+__device__ __forceinline__ void ldNa(const uint8_t* W, uint32_t off, uint64_t (&x)[N]) {
+  const uint32_t* w = (const uint32_t*)(W + (off & ~3u));
+  uint32_t d[2 * N + 1];
+#pragma unroll
+  for (int u = 0; u < 2 * N + 1; u++) d[u] = w[u];
+#pragma unroll
+  for (int u = 0; u < N; u++) x[u] = ((uint64_t)alignb(d[2 * u + 2], d[2 * u + 1], off) << 32) | alignb(d[2 * u + 1], d[2 * u], off);
+}
+
 // bucket cursors: two 16-bit counters per dword (values <= 65533), updated with 32-bit LDS atomics
 __device__ __forceinline__ uint32_t cur_get(const uint32_t* c, uint32_t h) { return (c[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu; }
 __device__ __forceinline__ uint32_t cur_inc(uint32_t* c, uint32_t h) {
@@ -329,8 +355,10 @@ __device__ unsigned long long g_dfl_stamps[3][16];
 // (low-253) at distance (high half).
 __host__ __device__ __forceinline__ uint32_t rec_ntok_off() { return 1280u; }
 __host__ __device__ __forceinline__ uint32_t rec_tok_off() { return 1296u; }
-__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return 1296u + 4u * L; }
-__host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L) { return (rec_slot_off(L) + L + 5u + 255u) & ~255u; }
+// The slot starts 16-byte aligned and carries 16 bytes beyond the largest stream (L + 5): the encode kernel copies its bit
+// image out in whole 16-byte stores, which must stay inside this record (the neighbour's histogram follows).
+__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return 1296u + 4u * ((L + 3u) & ~3u); }
+__host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L) { return (rec_slot_off(L) + L + 5u + 16u + 255u) & ~255u; }
 
 struct Args {
   const uint8_t* data; uint64_t n;
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (lane == leader) base = atomicAdd(&sm.qhead, (uint32_t)__builtin_popcountll(need));
           base = (uint32_t)__shfl((int)base, (int)leader, 64);
           if (st == FETCH) {
-            const uint32_t ii = base + (uint32_t)__builtin_popcountll(need & lanemask_lt());
+            const uint32_t ii = base + mbcnt64(need);
             if (ii >= nh) st = DONE;
             else {
               const uint32_t pp = S[ii];
@@ -521,7 +549,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
                 i = ii; p = pp;
                 qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
                 kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
-                pw0 = ld32(W + p); pw1 = ld32(W + p + 4);
+                ld64a(W, p, pw0, pw1);
                 const uint32_t h = hash4(pw0);
                 const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
                 maxlen = (T - p) < MAXM ? (T - p) : MAXM;
@@ -561,8 +589,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
           else {
             // random-address window reads only for candidates that can still win
-            const uint32_t cprobe = ld32(W + q + best - 3);
-            const uint32_t c0 = ld32(W + q), c1 = ld32(W + q + 4);
+            const uint32_t cprobe = ld32a(W, q + best - 3);
+            uint32_t c0, c1;
+            ld64a(W, q, c0, c1);
             uint32_t x;
             if (cprobe != probe) { }                                   // cannot beat the current best
             else if ((x = c0 ^ pw0) != 0) ml = (uint32_t)__builtin_ctz(x) >> 3;
@@ -576,8 +605,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           // largest dictionary jobs)
           if constexpr (!LDSM || TCAP > 21504) {
             uint64_t da[8], db[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { __builtin_memcpy(&da[u], W + q + ml + 8 * u, 8); __builtin_memcpy(&db[u], W + p + ml + 8 * u, 8); }
+            ldNa<8>(W, q + ml, da); ldNa<8>(W, p + ml, db);
             uint32_t adv = 64;
             bool hit = false;
 #pragma unroll
@@ -585,12 +613,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             ml += adv;
             if (hit || ml >= maxlen) fin = true;
           } else {
-            uint64_t xa, xb, ya, yb, za, zb, wa, wb;
-            __builtin_memcpy(&xa, W + q + ml, 8); __builtin_memcpy(&xb, W + p + ml, 8);
-            __builtin_memcpy(&ya, W + q + ml + 8, 8); __builtin_memcpy(&yb, W + p + ml + 8, 8);
-            __builtin_memcpy(&za, W + q + ml + 16, 8); __builtin_memcpy(&zb, W + p + ml + 16, 8);
-            __builtin_memcpy(&wa, W + q + ml + 24, 8); __builtin_memcpy(&wb, W + p + ml + 24, 8);
-            const uint64_t x = xa ^ xb, y = ya ^ yb, z = za ^ zb, w = wa ^ wb;
+            uint64_t qa[4], pa[4];
+            ldNa<4>(W, q + ml, qa); ldNa<4>(W, p + ml, pa);
+            const uint64_t x = qa[0] ^ pa[0], y = qa[1] ^ pa[1], z = qa[2] ^ pa[2], w = qa[3] ^ pa[3];
             if (x) { ml += (uint32_t)__builtin_ctzll(x) >> 3; fin = true; }
             else if (y) { ml += 8 + ((uint32_t)__builtin_ctzll(y) >> 3); fin = true; }
             else if (z) { ml += 16 + ((uint32_t)__builtin_ctzll(z) >> 3); fin = true; }
@@ -603,7 +628,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           bool pos_done = false;
           if (ml > best) {
             best = ml; bd = (bd & 0x80000000u) | (p - q);
-            if (ml == maxlen) pos_done = true; else probe = ld32(W + p + best - 3);
+            if (ml == maxlen) pos_done = true; else probe = ld32a(W, p + best - 3);
           }
           if (++kk > kmax) pos_done = true;
           st = PROBE;
@@ -1023,7 +1048,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
   __syncthreads();
   const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
-  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // slot is 16-byte aligned and padded
+  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned and has 16 bytes of slack (rec_size)
     const uint4 v = *(const uint4*)((const uint8_t*)out + i);
     *(uint4*)(slot + i) = v;
   }
@@ -1252,6 +1277,8 @@ extern "C" int hmse_debug_deflate_stamps(unsigned long long* out48, int reset) {
   return HMSE_OK;
 }
 #endif
+
+extern "C" uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len) { return chunk_len <= 32768u ? dfl::rec_size(chunk_len) : 0u; }
 
 // fixed part only; the caller adds the slot area: sum over chunks of align16(len+5) * (1 + has_base)
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_sel, const hmse_cfg*) { return dfl::carve(nullptr, n_sel).fixed_bytes; }

@@ -36,7 +36,11 @@ struct Args {
   uint32_t* trace;  // diagnostics only (tools/inflate_debug.py): host-visible progress words, 8 per wavefront
 };
 
+#ifdef HMSE_DIAG
 #define IFL_TRACE(slot, val) do { if (a.trace && lane == 0) __hip_atomic_store(&a.trace[(blockIdx.x * (NT / 64) + wave) * 8 + (slot)], (uint32_t)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define IFL_TRACE(slot, val) do { } while (0)
+#endif
 
 // CONVERGENCE RULE of this file: the compiler does not promise that lanes which skipped an `if (lane == ...)` block
 // wait for the others before the next wave-level operation (readfirstlane, ballot, readlane) — with such a block at
@@ -344,9 +348,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint64_t* __restric
 
 }  // namespace ifl
 
+#ifdef HMSE_DIAG
 static uint32_t* g_ifl_trace = nullptr;
 // diagnostics hook, not part of the ABI: progress words in host-visible memory (tools/inflate_debug.py)
 extern "C" void hmsedbg_inflate_trace(void* p) { g_ifl_trace = (uint32_t*)p; }
+#else
+static uint32_t* const g_ifl_trace = nullptr;
+#endif
 
 size_t hmse_l1_inflate_workspace_bytes_impl(uint64_t n_sel) { return 256 + hmse_align_up((size_t)n_sel * 4, 256); }
 

@@ -151,10 +151,12 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
   if (n_sel > 0x7FFFFFFFull) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
-  // tuning switch for tools/stage_bench.py only (threads per workgroup x instruction variant); the default is the measured best
-  static const int variant = getenv("HMSE_MH_VARIANT") ? atoi(getenv("HMSE_MH_VARIANT")) : MH_DEFAULT_VARIANT;
   const dim3 grid((uint32_t)n_sel);
   PROF_BEGIN(HMSE_STAGE_L4_MINHASH, stream);
+#ifdef HMSE_DIAG
+  // diagnostic build only (libhmse_hip_diag.so, tools/minhash_variants.py): threads per workgroup x instruction variant;
+  // variants 6 and 7 are timing probes that return WRONG signatures, which is why none of this is in the product library
+  static const int variant = getenv("HMSE_MH_VARIANT") ? atoi(getenv("HMSE_MH_VARIANT")) : MH_DEFAULT_VARIANT;
   switch (variant) {
     case 0: l4_minhash_kernel<256, 0><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
     case 1: l4_minhash_kernel<256, 1><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
@@ -165,6 +167,9 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
     case 7: l4_minhash_kernel<1024, 3><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;  // timing probe: no inserts
     default: l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
   }
+#else
+  l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig);
+#endif
   PROF_END(HMSE_STAGE_L4_MINHASH, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;

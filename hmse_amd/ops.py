@@ -152,6 +152,11 @@ def l4_lsh(sig: torch.Tensor, cfg: IngestConfig):
     return keys, base
 
 
+def record_bytes(lens: torch.Tensor) -> torch.Tensor:
+    """hmse_l1_deflate_record_bytes() for a tensor of chunk lengths (<= 32768)."""
+    return (1296 + 4 * ((lens + 3) & ~3) + lens + 5 + 16 + 255) & ~255
+
+
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
                base: torch.Tensor | None = None, base_is_chunk_id: bool = False):
     """Per-chunk raw DEFLATE with the base chunk as dictionary (`base`: index into the selection, or — with
@@ -167,8 +172,9 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     if n_sel <= 0:
         return torch.empty(0, dtype=torch.uint8, device=dev), out_off, kind
     lens = (cuts[1:] - cuts[:-1]) if chunk_ids is None else (cuts[chunk_ids + 1] - cuts[chunk_ids])
-    # per-job record of the C-ABI workspace (hmse_amd/csrc/l1_deflate.hip rec_size(): histograms, token list, stream slot)
-    rec = (1296 + 4 * lens + lens + 5 + 255) & ~255
+    # per-job record of the C-ABI workspace = hmse_l1_deflate_record_bytes(len) (histograms, token list, 16-byte aligned
+    # stream slot with 16 bytes of slack), evaluated on the device; tests/test_abi.py holds the two formulas together
+    rec = record_bytes(lens)
     nvar = 1 if base is None else 1 + (base >= 0).to(torch.int64)
     raw, need = (int(v) for v in torch.stack([lens.sum(), (rec * nvar).sum()]).tolist())
     cap = raw + 5 * n_sel + 64  # a stored block is the worst case

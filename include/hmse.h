@@ -171,13 +171,17 @@ int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* cfg, uint32
  *   kind      DEVICE u8[n_sel]: HMSE_KIND_FULL or HMSE_KIND_DELTA
  *   status    DEVICE u32[1]: bit0 = out_cap overflow (out_off still exact), bit1 = workspace too small
  *   ws        hmse_workspace_bytes(HMSE_STAGE_L1_DEFLATE, n_sel, cfg) is the FIXED part; after it the call needs
- *             one job record per encode (FULL, plus DELTA where base >= 0) of about 5*len + 1.6 KiB bytes
- *             (exact formula: rec_size() in hmse_amd/csrc/l1_deflate.hip, mirrored by hmse_amd/ops.py)
+ *             one job record per encode (FULL, plus DELTA where base >= 0) of hmse_l1_deflate_record_bytes(len)
+ *             bytes each (about 5*len + 1.6 KiB)
  */
 int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const uint64_t* chunk_ids, const int64_t* base, uint64_t n_sel,
                     const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
                     uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/* Bytes of workspace one encode of a chunk of `chunk_len` bytes needs behind the fixed part (0 if chunk_len > 32768:
+ * such a chunk cannot be encoded — `uint16_t length`, README.md:1267). */
+uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len);
 
 /*
  * L1 with options (the streaming front end): as hmse_l1_deflate, plus

@@ -28,6 +28,35 @@ def test_library_exports_every_declared_symbol():
     assert lib.hmse_abi_version() == 1
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """exported == declared: no diagnostic hook or probe entry point ships in the product library."""
+    import subprocess
+    from hmse_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.HIP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[1:2] and ln.split()[1] in "TW"}
+    c_abi = sorted(s for s in exported if not s.startswith("_"))
+    undeclared = [s for s in c_abi if s not in set(declared_functions()) and not s.startswith("__hip")]
+    assert undeclared == [], undeclared
+    assert [s for s in c_abi if s.startswith("hmsedbg")] == []
+    src = "".join(open(os.path.join(ROOT, "hmse_amd", "csrc", f)).read() for f in ("l4_minhash.hip", "l1_inflate.hip"))
+    assert src.count("#ifdef HMSE_DIAG") >= 3 and "getenv" not in re.sub(r"#ifdef HMSE_DIAG.*?#e(lse|ndif)", "", src, flags=re.S)
+
+
+def test_deflate_record_bytes_formula_matches_the_abi():
+    """ops.record_bytes (evaluated on the device for a whole shard) == hmse_l1_deflate_record_bytes for every chunk length,
+    the slot is 16-byte aligned and leaves 16 bytes behind the largest stream (the encode kernel's 16-byte copy-out)."""
+    import torch
+    from hmse_amd import _lib, ops
+    lib = _lib.hip_lib()
+    lens = torch.arange(0, 32769, dtype=torch.int64)
+    got = ops.record_bytes(lens).numpy()
+    want = np.array([lib.hmse_l1_deflate_record_bytes(int(v)) for v in range(32769)], dtype=np.int64)
+    assert np.array_equal(got, want)
+    slot = 1296 + 4 * ((lens.numpy() + 3) & ~3)
+    assert (slot % 16 == 0).all() and (want - slot - (lens.numpy() + 5) >= 16).all() and (want % 256 == 0).all()
+    assert lib.hmse_l1_deflate_record_bytes(32769) == 0
+
+
 def test_cfg_default_matches_oracle_and_dataclass(orc):
     from hmse_amd import IngestConfig, _lib
     lib = _lib.hip_lib()

@@ -205,6 +205,41 @@ def test_l1_deflate_edges(orc, dev):
     assert want_kind[9] == 2 and want_kind[5] == 0
 
 
+def test_l1_deflate_near_incompressible_record_slots(orc, dev):
+    """Streams whose size is within a byte of the stored size (L + 4 of L + 5), at 256 consecutive chunk lengths: the
+    encode kernel copies its bit image out in whole 16-byte stores, which must not reach the neighbouring job record
+    (its literal histogram) whatever the record padding is — every stream must still equal the oracle's."""
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    oc = ocfg(orc, cfg)
+    rng = np.random.Generator(np.random.PCG64(1234))
+    parts = []
+    for L in range(1500, 1756):
+        body = rng.integers(0, 256, L, dtype=np.uint8)
+        for t in range(16, 96):   # a repeated tail just long enough for the dynamic block to beat the stored one
+            c = body.copy(); c[L - t:] = c[:t]
+            out, off, _ = orc.deflate_chunks(c, np.array([0, L], dtype=np.uint64), oc, None, None)
+            if ((out[0] >> 1) & 3) != 0 and int(off[1]) <= L + 4:
+                break
+        else:
+            raise AssertionError("no near-incompressible variant found")
+        assert L - 8 < int(off[1]) <= L + 4
+        parts.append(c)
+    order = rng.permutation(len(parts))
+    parts = [parts[i] for i in order]
+    data = np.concatenate(parts)
+    cuts = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    base = np.full(len(parts), -1, dtype=np.int64)
+    base[3::4] = np.arange(3, len(parts), 4) - 2   # some jobs also carry a (useless) dictionary: FULL + DELTA records side by side
+    want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, oc, None, base)
+    d_data, d_cuts, d_base = to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), to_dev(base, dev)
+    for _ in range(3):   # the jobs run concurrently: an overrun would hit a neighbour only some of the time
+        out, off, kind = ops.l1_deflate(d_data, d_cuts, cfg, None, d_base)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(kind.cpu().numpy(), want_kind)
+        assert np.array_equal(out.cpu().numpy(), want_out)
+
+
 def test_l1_deflate_selection(orc, dev, corpus_small):
     from hmse_amd import IngestConfig, ops
     cfg = IngestConfig()

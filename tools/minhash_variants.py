@@ -2,7 +2,8 @@
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hmse_amd import IngestConfig, corpus, ops
+from hmse_amd import IngestConfig, _lib, corpus, ops
+_lib.HIP_LIB_PATH = _lib.HIP_LIB_PATH.replace("libhmse_hip.so", "libhmse_hip_diag.so")  # make -C hmse_amd/csrc libhmse_hip_diag.so
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 dev = torch.device("cuda:0")
 cfg = IngestConfig()
