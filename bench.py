@@ -48,52 +48,77 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--layers", default="full", help="ablation preset (hmse_amd.config.ABLATIONS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample (0 = 4 MiB x 2 x cores, <= 128 MiB)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample (0 = 4 MiB x 2 x cores, <= 256 MiB)")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------ CPU leg
 def _cpu_segment(args):
-    """Oracle path over one 4 MiB segment (runs in a worker process): the reference's CPU pipeline."""
+    """The reference's CPU pipeline over one 4 MiB segment (runs in a worker process), same scope as one GPU shard of that
+    segment: oracle FastCDC -> hashlib.sha256 -> first-occurrence dedupe -> oracle MinHash/LSH on the unique chunks ->
+    zlib level 9 (raw, zdict = LSH base) per unique chunk."""
     import hashlib
     import zlib
     seg, cfg_kw = args
     from oracle import oracle as O
     cfg = O.default_cfg(**cfg_kw)
     cuts = O.cdc(seg, cfg)
-    digs = [hashlib.sha256(seg[int(cuts[i]):int(cuts[i + 1])]).digest() for i in range(len(cuts) - 1)]
-    sig = O.minhash_chunks(seg, cuts, cfg)
+    n = len(cuts) - 1
+    digs = np.frombuffer(b"".join(hashlib.sha256(seg[int(cuts[i]):int(cuts[i + 1])]).digest() for i in range(n)), np.uint8).reshape(n, 32)
+    fo, _ = O.dedup(digs)
+    uniq = np.nonzero(fo == np.arange(n))[0].astype(np.uint64)
+    sig = O.minhash_chunks(seg, cuts, cfg, uniq)
     _, base = O.lsh(sig, cfg)
     stored = 0
-    for i in range(len(cuts) - 1):
-        c = seg[int(cuts[i]):int(cuts[i + 1])].tobytes()
-        zd = seg[int(cuts[base[i]]):int(cuts[base[i] + 1])].tobytes() if base[i] >= 0 else None
-        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, zd) if zd else \
-            zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY)
-        stored += len(co.compress(c) + co.flush())
-    return len(digs), stored
+    for k, c in enumerate(uniq):
+        ch = seg[int(cuts[c]):int(cuts[c + 1])].tobytes()
+        b = int(uniq[base[k]]) if base[k] >= 0 else -1
+        if b >= 0:
+            co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, seg[int(cuts[b]):int(cuts[b + 1])].tobytes())
+            delta = len(co.compress(ch) + co.flush())
+        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY)
+        full = len(co.compress(ch) + co.flush())
+        stored += delta if b >= 0 and delta + 8 < full else full     # the delta rule of SURVEY.md D7
+    return n, stored, cuts, uniq, base
+
+
+def _cpu_segment_oracle_deflate(args):
+    """Untimed second pass: the build's own encoder definition (oracle DEFLATE) over the same chunks and bases."""
+    seg, cfg_kw, cuts, uniq, base = args
+    from oracle import oracle as O
+    _, off, _ = O.deflate_chunks(seg, cuts, O.default_cfg(**cfg_kw), uniq, base)
+    return int(off[-1])
 
 
 def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
-    """The Python zlib/hashlib + oracle CPU path on a bounded sample, all host cores."""
+    """The Python zlib/hashlib + oracle CPU path on a bounded sample: all host cores, and one core.
+    Runs BEFORE the process touches the GPU (it forks workers)."""
     import multiprocessing as mp
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
     seg = 4 << 20
-    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 32)
+    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 64)
     nseg = max(1, min(nseg, host.size // seg))
     segs = [(host[i * seg:(i + 1) * seg], {}) for i in range(nseg)]
     workers = min(cores, nseg)
     t0 = time.time()
+    _cpu_segment(segs[0])
+    dt1 = time.time() - t0
     with mp.get_context("fork").Pool(workers) as pool:
+        t0 = time.time()
         res = pool.map(_cpu_segment, segs)
-    dt = time.time() - t0
+        dt = time.time() - t0
+        stored_orc = sum(pool.map(_cpu_segment_oracle_deflate, [(s[0], s[1], r[2], r[3], r[4]) for s, r in zip(segs, res)]))
     nbytes = nseg * seg
-    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": workers, "kind": "port",
-            "sample": f"first {nseg} x 4 MiB segments of the same corpus ({nbytes >> 20} MiB): oracle FastCDC + hashlib.sha256 + "
-                      f"oracle MinHash/LSH + zlib level 9 (raw, zdict=LSH base), one segment per worker",
-            "seconds": round(dt, 2), "cf_payload_zlib9": nbytes / max(1, sum(r[1] for r in res))}
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": workers, "host_cores": cores, "kind": "port",
+            "one_core_GiB_per_s": seg / dt1 / 2**30,
+            "sample": f"first {nseg} x 4 MiB segments of the same corpus ({nbytes >> 20} MiB), each segment its own dedupe/LSH scope: oracle "
+                      f"FastCDC + hashlib.sha256 + dedupe + oracle MinHash/LSH + zlib level 9 (raw, zdict = LSH base, delta rule), one "
+                      f"segment per worker; one_core = the first segment alone",
+            "seconds": round(dt, 2), "sample_bytes": nbytes, "n_segments": nseg,
+            "cf_payload_zlib9_same_sample": nbytes / max(1, sum(r[1] for r in res)),
+            "cf_payload_oracle_deflate_same_sample": nbytes / max(1, stored_orc), "stored_bytes_oracle_deflate": stored_orc}
 
 
 def measured_traffic(kernel: str, total_bytes: int, world: int):
@@ -108,6 +133,15 @@ def measured_traffic(kernel: str, total_bytes: int, world: int):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def valu_issue_note():
+    """VALU-busy fraction per kernel family from the committed SQ counter passes (profiles/sq_valu.json, written by
+    tools/make_sq.py from rocprofv3 --pmc runs): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "sq_valu.json")))
+    except (OSError, ValueError):
+        return None
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -127,14 +161,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # HMSE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, reductions) even at world size 1
-    distributed = world > 1 or os.environ.get("HMSE_BENCH_FORCE_DIST") == "1"
-    if distributed:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
     cfg = IngestConfig(layers=ABLATIONS[a.layers])
     seg = cfg.seg_size
     total = int(a.bytes) if a.scaling == "strong" else int(a.bytes) * world
@@ -146,6 +172,20 @@ def main():
     t0 = time.time()
     host, source = corpus.load(a.corpus, n_local, first_byte=s0 * seg)
     t_gen = time.time() - t0
+    # CPU baseline leg first: it forks worker processes, which must happen before this process initialises the GPU
+    cpu = None
+    if not a.no_cpu_baseline and world == 1 and a.layers == "full":
+        try:
+            cpu = cpu_baseline(host, a.cpu_sample_mib)
+        except Exception as e:  # noqa: BLE001 — the baseline leg must not lose the GPU measurement
+            cpu = {"error": repr(e)}
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # HMSE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, reductions) even at world size 1
+    distributed = world > 1 or os.environ.get("HMSE_BENCH_FORCE_DIST") == "1"
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
     t0 = time.time()
     data = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize()
@@ -287,17 +327,35 @@ def main():
         }
         if dom:
             r = stage_roof[dom]
+            # stages = groups of kernels: the DEFLATE match kernels run as up to twelve launches (size class x plain/dictionary)
+            groups = {"L1 DEFLATE match (l1_deflate_kernel, all size classes)": "l1_deflate_kernel", "L1 DEFLATE encode (l1_encode_kernel)": "l1_encode_kernel",
+                      "L4 MinHash (l4_minhash_kernel)": "l4_minhash_kernel", "L3 SHA-256 (l3_sha256_kernel)": "l3_sha256_kernel", "L2 Gear hash (l2_hash_kernel)": "l2_hash_kernel"}
+            stage_ms = {g: sum(v["avg_ms"] for k, v in stage_roof.items() if k.startswith(pre)) for g, pre in groups.items()}
+            stage_alg = {g: sum(v["alg_bytes"] for k, v in stage_roof.items() if k.startswith(pre)) for g, pre in groups.items()}
+            dstage = max(stage_ms, key=stage_ms.get)
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": r["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": r["frac_hbm"], "traffic": measured_traffic(dom, tot["bytes"], world),
-                               "note": "integer-VALU/LDS-bound kernel priced against the HBM roof (SURVEY.md §8d); rank 0" + VALU_NOTE.get(dom, "")}
+                               "dominant_stage": {"stage": dstage, "ms_per_step": round(stage_ms[dstage], 2),
+                                                  "share_of_step": round(stage_ms[dstage] / (dt / a.steps * 1e3), 3),
+                                                  "achieved_GBps": round(stage_alg[dstage] / max(stage_ms[dstage], 1e-9) / 1e6, 2),
+                                                  "frac_hbm": round(stage_alg[dstage] / max(stage_ms[dstage], 1e-9) / 1e6 / HBM_PEAK_GBPS, 5)},
+                               "valu_issue": valu_issue_note(),
+                               "note": "`kernel` = the longest single launch, `dominant_stage` = the longest group of launches; both are "
+                                       "integer-VALU/LDS-bound and priced against the HBM roof (SURVEY.md §8d); rank 0" + VALU_NOTE.get(dom, "")}
         out["stage_roofline"] = stage_roof
         if read_info:
             out["read_path"] = read_info
-        if not a.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(host, a.cpu_sample_mib)
-            except Exception as e:  # noqa: BLE001 — the baseline leg must not lose the GPU measurement
-                out["cpu_baseline"] = {"error": repr(e)}
+        if cpu is not None:
+            if "n_segments" in cpu:
+                # the GPU path over the SAME sample and scope as the CPU leg (every 4 MiB segment its own shard): its stored
+                # bytes must equal the oracle encoder's exactly (bit-exact streams), zlib-9's CF is the reference point
+                stored_gpu = 0
+                for i in range(cpu["n_segments"]):
+                    r = ingest.ingest_shard(data[i * seg:(i + 1) * seg], cfg, want_stats=True)
+                    stored_gpu += r.stats["stored_bytes"]
+                cpu["cf_payload_gpu_same_sample"] = cpu["sample_bytes"] / max(1, stored_gpu)
+                cpu["gpu_stored_bytes_equal_oracle_deflate"] = bool(stored_gpu == cpu.pop("stored_bytes_oracle_deflate"))
+            out["cpu_baseline"] = cpu
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()

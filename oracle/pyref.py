@@ -130,3 +130,258 @@ def lsh(sigs, bands=4, rows=32):
                 break
         base.append(found)
     return keys, base
+
+
+# ---------------------------------------------------------------------------------------------
+# L1: the build's DEFLATE encoder definition, restated independently of oracle/hmse_oracle_deflate.c
+# (written from the six numbered rules in that file's header and from RFC 1951, sharing no code with
+# it: dictionaries of bucket lists instead of a counting sort, Python deques for the two-queue
+# Huffman, one big integer as bit buffer).  tests/test_oracle.py holds the two together byte for
+# byte on small inputs; the definition itself stays "parity unpinned" at the reference (README.md
+# names miniz level 9, whose serial lazy matcher a parallel encoder cannot reproduce: SURVEY.md §7).
+# ---------------------------------------------------------------------------------------------
+_LEVEL_DEPTH = (2, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+_CL_ORDER = (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15)
+# RFC 1951 §3.2.5 tables, written out (the C oracle uses closed forms)
+_LEN_BASE = (3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258)
+_LEN_EXTRA = (0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0)
+_DIST_BASE = (1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+              8193, 12289, 16385, 24577)
+_DIST_EXTRA = (0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13)
+
+
+def _len_code(length):
+    for c in range(28, -1, -1):
+        if length >= _LEN_BASE[c]:
+            return 257 + c, _LEN_EXTRA[c], length - _LEN_BASE[c]
+    raise ValueError(length)
+
+
+def _dist_code(dist):
+    for c in range(29, -1, -1):
+        if dist >= _DIST_BASE[c]:
+            return c, _DIST_EXTRA[c], dist - _DIST_BASE[c]
+    raise ValueError(dist)
+
+
+def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
+    """Rules 1-2: per chunk position the longest match among its `depth` nearest bucket predecessors."""
+    dict_ = dict_[-32768:]
+    w = dict_ + chunk
+    t, dl = len(w), len(dict_)
+    buckets = {}
+    for q in range(t - 3):
+        h = ((int.from_bytes(w[q:q + 4], "little") * 0x9E3779B1) & M32) >> 20
+        buckets.setdefault(h, []).append(q)
+    where = {}
+    for members in buckets.values():
+        for r, q in enumerate(members):
+            where[q] = (members, r)
+    mlen, mdist = [0] * len(chunk), [0] * len(chunk)
+    for p in range(dl, t - 3):
+        members, r = where[p]
+        cap = min(258, t - p)
+        best, bdist = 3, 0
+        for q in reversed(members[max(0, r - depth):r]):   # nearest first
+            if p - q > 32768:
+                break
+            n = 0
+            while n < cap and w[q + n] == w[p + n]:
+                n += 1
+            if n > best:
+                best, bdist = n, p - q
+                if n == cap:
+                    break
+        if best >= 4:
+            mlen[p - dl], mdist[p - dl] = best, bdist
+    return mlen, mdist
+
+
+def lz_parse(chunk: bytes, mlen, mdist):
+    """Rule 3: one-step lazy parse -> list of (literal byte, 0) / (length, distance)."""
+    toks, p, n = [], 0, len(chunk)
+    while p < n:
+        here = mlen[p]
+        nxt = mlen[p + 1] if p + 1 < n else 0
+        if here >= 4 and not nxt > here:
+            toks.append((here, mdist[p]))
+            p += here
+        else:
+            toks.append((chunk[p], 0))
+            p += 1
+    return toks
+
+
+def huffman_lengths(freq, limit):
+    """Rule 5: two-queue Huffman over (freq, index)-sorted leaves, leaf wins ties; depths clamped to `limit`, Kraft repair,
+    lengths handed out in sorted order (most frequent = shortest)."""
+    from collections import deque
+    freq = list(freq)
+    for i in range(len(freq)):             # fewer than two used symbols: the lowest unused indices count once
+        if sum(1 for f in freq if f) >= 2:
+            break
+        if not freq[i]:
+            freq[i] = 1
+    leaves = sorted((f, s) for s, f in enumerate(freq) if f)
+    m = len(leaves)
+    # nodes: (weight, [leaf ranks below it]); depth of a leaf = number of merges it took part in
+    depth = [0] * m
+    lq = deque((f, [r]) for r, (f, _) in enumerate(leaves))
+    iq = deque()
+    while len(lq) + len(iq) > 1:
+        picked = []
+        for _ in range(2):
+            if lq and (not iq or lq[0][0] <= iq[0][0]):
+                picked.append(lq.popleft())
+            else:
+                picked.append(iq.popleft())
+        below = picked[0][1] + picked[1][1]
+        for r in below:
+            depth[r] += 1
+        iq.append((picked[0][0] + picked[1][0], below))
+    count = [0] * (limit + 1)
+    for d in depth:
+        count[min(d, limit)] += 1
+    total = sum(count[i] << (limit - i) for i in range(1, limit + 1))
+    while total > (1 << limit):            # over-subscribed after clamping: miniz-style repair
+        count[limit] -= 1
+        for i in range(limit - 1, 0, -1):
+            if count[i]:
+                count[i] -= 1
+                count[i + 1] += 2
+                break
+        total -= 1
+    lens = [0] * len(freq)
+    rank = m
+    for length in range(1, limit + 1):
+        for _ in range(count[length]):
+            rank -= 1
+            lens[leaves[rank][1]] = length
+    return lens
+
+
+def canonical_codes(lens):
+    """RFC 1951 §3.2.2; returned bit-reversed (DEFLATE packs Huffman codes MSB first into an LSB-first stream)."""
+    per_len = [0] * 16
+    for n in lens:
+        if n:
+            per_len[n] += 1
+    nxt, code = [0] * 16, 0
+    for bits in range(1, 16):
+        code = (code + per_len[bits - 1]) << 1
+        nxt[bits] = code
+    out = []
+    for n in lens:
+        if not n:
+            out.append(0)
+            continue
+        c = nxt[n]
+        nxt[n] += 1
+        out.append(int(format(c, "0%db" % n)[::-1], 2))
+    return out
+
+
+def rle_code_lengths(lens):
+    """Rule 6 for one tree -> list of (symbol, extra bits, extra value)."""
+    out, i, n = [], 0, len(lens)
+    while i < n:
+        j = i
+        while j < n and lens[j] == lens[i]:
+            j += 1
+        run, v = j - i, lens[i]
+        if v == 0:
+            while run >= 11:
+                c = min(run, 138)
+                out.append((18, 7, c - 11))
+                run -= c
+            if run >= 3:
+                out.append((17, 3, run - 3))
+                run = 0
+            out.extend([(0, 0, 0)] * run)
+        else:
+            out.append((v, 0, 0))
+            run -= 1
+            while run >= 3:
+                c = min(run, 6)
+                out.append((16, 2, c - 3))
+                run -= c
+            out.extend([(v, 0, 0)] * run)
+        i = j
+    return out
+
+
+class _Bits:
+    def __init__(self):
+        self.acc, self.n = 0, 0
+
+    def put(self, value, nbits):
+        self.acc |= value << self.n
+        self.n += nbits
+
+    def align(self):
+        self.n = (self.n + 7) & ~7
+
+    def bytes(self):
+        self.align()
+        return self.acc.to_bytes(self.n // 8, "little")
+
+
+def deflate(chunk: bytes, dict_: bytes = b"", level: int = 9, chain_depth: int = 0) -> bytes:
+    """The whole encoder (rules 1-6): one final block, smallest of stored / fixed / dynamic (ties: stored, then fixed)."""
+    depth = chain_depth or _LEVEL_DEPTH[min(level, 9)]
+    mlen, mdist = lz_matches(chunk, dict_, depth)
+    toks = lz_parse(chunk, mlen, mdist)
+    lf, df, extra = [0] * 286, [0] * 30, 0
+    for a, d in toks:
+        if d:
+            c, eb, _ = _len_code(a)
+            lf[c] += 1
+            extra += eb
+            c, eb, _ = _dist_code(d)
+            df[c] += 1
+            extra += eb
+        else:
+            lf[a] += 1
+    lf[256] += 1
+    fixed_ll = [8] * 144 + [9] * 112 + [7] * 24 + [8] * 8
+    fixed_bits = 3 + extra + sum(f * fixed_ll[s] for s, f in enumerate(lf)) + 5 * sum(df)
+    ll, dl = huffman_lengths(lf, 15), huffman_lengths(df, 15)
+    nlit = max(257, max(s + 1 for s in range(286) if ll[s]))
+    ndist = max(1, max((s + 1 for s in range(30) if dl[s]), default=1))
+    rle = rle_code_lengths(ll[:nlit]) + rle_code_lengths(dl[:ndist])
+    cf = [0] * 19
+    for s, _, _ in rle:
+        cf[s] += 1
+    cl = huffman_lengths(cf, 7)
+    ncl = max(4, max(i + 1 for i in range(19) if cl[_CL_ORDER[i]]))
+    dyn_bits = 3 + 14 + 3 * ncl + extra + sum(cl[s] + eb for s, eb, _ in rle) \
+        + sum(f * ll[s] for s, f in enumerate(lf)) + sum(f * dl[s] for s, f in enumerate(df))
+    stored_bits = 8 * (5 + len(chunk))
+    b = _Bits()
+    if stored_bits <= fixed_bits and stored_bits <= dyn_bits:
+        b.put(1, 1); b.put(0, 2); b.align()
+        b.put(len(chunk) & 0xFFFF, 16); b.put(~len(chunk) & 0xFFFF, 16)
+        return b.bytes() + chunk
+    if fixed_bits <= dyn_bits:
+        ll, dl = fixed_ll, [5] * 32
+        lc, dc = canonical_codes(ll), canonical_codes(dl)
+        b.put(1, 1); b.put(1, 2)
+    else:
+        lc, dc, cc = canonical_codes(ll), canonical_codes(dl), canonical_codes(cl)
+        b.put(1, 1); b.put(2, 2)
+        b.put(nlit - 257, 5); b.put(ndist - 1, 5); b.put(ncl - 4, 4)
+        for i in range(ncl):
+            b.put(cl[_CL_ORDER[i]], 3)
+        for s, eb, ev in rle:
+            b.put(cc[s], cl[s])
+            b.put(ev, eb)
+    for a, d in toks:
+        if d:
+            c, eb, ev = _len_code(a)
+            b.put(lc[c], ll[c]); b.put(ev, eb)
+            c, eb, ev = _dist_code(d)
+            b.put(dc[c], dl[c]); b.put(ev, eb)
+        else:
+            b.put(lc[a], ll[a])
+    b.put(lc[256], ll[256])
+    return b.bytes()

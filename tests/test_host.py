@@ -1,5 +1,6 @@
 """CPU: host-side logic — corpus generator, manifest records (the reference's packed structs), stats."""
 import hashlib
+import os
 import zlib
 
 import numpy as np
@@ -157,3 +158,21 @@ def test_parse_manifest_matches_the_oracle_records(orc):
     bad[o:o + 4] = np.frombuffer(np.uint32(0xFFFFFFF0).tobytes(), np.uint8)
     with pytest.raises(read.ReadError):
         read.parse_manifest(manifest.Manifest(m.lba_unit, m.index, m.chunk_map, m.pointers, bad))
+
+
+def test_oracle_pool_equals_the_serial_oracle_pipeline(orc):
+    """tests/oracle_pool.py (the oracle with MinHash and DEFLATE spread over spawned workers, used by the at-scale GPU
+    parity test) returns exactly what the serial pipeline returns, slices and cross-slice dictionaries included."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import oracle_pool
+    from make_golden import variants_dataset
+    from test_gpu_ingest import oracle_pipeline
+    from hmse_amd import IngestConfig, corpus
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = np.concatenate([variants_dataset(corpus.wiki_synth(3 << 20, seed=42)), corpus.wiki_synth(1 << 20, seed=42)])
+    a = oracle_pool.pipeline(orc, data, cfg, workers=2, slices_per_worker=6)
+    _, (b,) = oracle_pipeline(orc, data, cfg)
+    assert (b["base"] >= 0).sum() > 10
+    for k in ("cuts", "dg", "fo", "uniq", "sig", "base", "out", "off", "kind"):
+        assert np.array_equal(a[k], b[k]), k

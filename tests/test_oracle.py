@@ -210,18 +210,100 @@ def test_deflate_dictionary_and_delta_rule(orc):
 
 
 def test_deflate_cf_close_to_zlib9(orc, corpus_small):
-    """CF sanity: >= 2:1 on Wikipedia-like text (README.md:2425) and within 2 % of zlib level 9 on the same chunks."""
+    """CF sanity: >= 2:1 on Wikipedia-like text (README.md:2425) and what DESIGN.md §2 states about zlib level 9 (the
+    codec README.md:2374 names): FULL streams are never more than 0.3 % larger in total than zlib-9's on the same chunks
+    (measured: 1.9-2.5 % smaller on the corpus profiles and on plain word text)."""
     cfg = orc.default_cfg()
-    data = corpus_small[: 1 << 20]
+    for data in (corpus_small[: 1 << 20], words_text(1 << 19, seed=3)):
+        cuts = orc.cdc(data, cfg)
+        mine = z9 = 0
+        for s, e in zip(cuts[:-1], cuts[1:]):
+            c = data[int(s):int(e)].tobytes()
+            mine += len(orc.deflate(c, cfg))
+            co = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
+            z9 += len(co.compress(c) + co.flush())
+        assert data.size / mine >= 2.0
+        assert mine <= 1.003 * z9
+
+
+def test_delta_records_close_to_zlib9_with_zdict(orc):
+    """DELTA records (raw DEFLATE with zdict = base chunk) against zlib level 9 given the same dictionary, on
+    the near-duplicate family of the golden fixtures: every record inflates through stock zlib with that dictionary, is
+    many times smaller than the FULL record, and the DELTA bytes in total stay within 5 % of zlib's (measured +2.3 % on
+    24 MiB of wiki-synth, +4.4 % here: ~10 bytes on records of ~250 bytes; depth 32 against zlib's 4096-deep chains)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import corpus
+    cfg = orc.default_cfg(seg_size=1 << 20)
+    data = variants_dataset(corpus.wiki_synth(3 << 20, seed=42))
     cuts = orc.cdc(data, cfg)
-    mine = z9 = 0
-    for s, e in zip(cuts[:-1], cuts[1:]):
-        c = data[int(s):int(e)].tobytes()
-        mine += len(orc.deflate(c, cfg))
-        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9)
-        z9 += len(co.compress(c) + co.flush())
-    assert data.size / mine >= 2.0
-    assert mine <= 1.02 * z9
+    fo, _ = orc.dedup(orc.sha256_chunks(data, cuts))
+    uniq = np.nonzero(fo == np.arange(len(fo)))[0].astype(np.uint64)
+    _, base = orc.lsh(orc.minhash_chunks(data, cuts, cfg, uniq), cfg)
+    out, off, kind = orc.deflate_chunks(data, cuts, cfg, uniq, base)
+    mine = zl = full = n = 0
+    for k in np.nonzero(kind == 2)[0]:
+        c = data[int(cuts[uniq[k]]):int(cuts[uniq[k] + 1])].tobytes()
+        b = uniq[base[k]]
+        d = data[int(cuts[b]):int(cuts[b + 1])].tobytes()
+        rec = out[int(off[k]):int(off[k + 1])].tobytes()
+        assert _rt(rec, d) == c
+        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, d)
+        zl += len(co.compress(c) + co.flush())
+        mine += len(rec)
+        full += len(orc.deflate(c, cfg))
+        n += 1
+    assert n >= 20
+    assert mine <= 1.05 * zl and mine * 8 < full
+
+
+def test_deflate_c_oracle_equals_python_restatement(orc):
+    """The encoder DEFINITION is this build's own (parity unpinned at the reference): it is pinned here by two
+    restatements that share no code — oracle/hmse_oracle_deflate.c and oracle/pyref.py — agreeing byte for byte on match
+    selection, lazy parse, block choice, Huffman lengths, code-length RLE and bit packing, over inputs that reach every
+    branch: tiny inputs, one-symbol runs, 2-/4-symbol alphabets (length-limited trees), incompressible bytes (stored),
+    barely compressible bytes (stored / fixed / dynamic ties), text, dictionaries, every level's depth."""
+    from oracle import pyref
+    rng = np.random.Generator(np.random.PCG64(99))
+    text = words_text(6000, seed=5).tobytes()
+    cases = [b"", b"a", b"ab", b"abc", b"abcd", b"abcde", b"aaaa", b"abcabcabcabc", bytes(300), bytes(3000), b"x" * 259, b"xy" * 700,
+             bytes(range(256)) * 3, text[:1], text[:37], text[:600], text[:2500], rng.integers(0, 256, 1200, dtype=np.uint8).tobytes(),
+             rng.integers(0, 2, 3000, dtype=np.uint8).tobytes(), rng.integers(0, 4, 2500, dtype=np.uint8).tobytes(),
+             rng.integers(0, 16, 1800, dtype=np.uint8).tobytes(), rng.integers(0, 250, 900, dtype=np.uint8).tobytes()]
+    for L in (700, 1300):   # random bytes with a repeated tail: sizes around the stored / dynamic break-even
+        body = rng.integers(0, 256, L, dtype=np.uint8)
+        for t in (20, 40, 48, 52, 56, 64, 90):
+            c = body.copy(); c[L - t:] = c[:t]
+            cases.append(c.tobytes())
+    # skewed frequencies: Fibonacci-like counts force depths beyond the 15-bit (and 7-bit code-length) limits -> Kraft repair
+    fib, skew = [1, 1], bytearray()
+    while len(fib) < 22:
+        fib.append(fib[-1] + fib[-2])
+    for sym, f in enumerate(fib):
+        skew += bytes([65 + sym]) * min(f, 4000)
+    perm = rng.permutation(len(skew))
+    cases.append(bytes(np.frombuffer(bytes(skew), np.uint8)[perm][:9000]))
+    block = {0: 0, 1: 0, 2: 0}
+    for c in cases:
+        for lvl in (9, 1):
+            cfg = orc.default_cfg(level=lvl)
+            want, got = orc.deflate(c, cfg), pyref.deflate(c, level=lvl)
+            assert want == got, (len(c), lvl)
+            block[(got[0] >> 1) & 3] += 1
+            assert _rt(got) == c
+    assert all(block.values()), block   # stored, fixed and dynamic blocks all occurred
+    var = bytearray(text[:2500]); var[100:104] = b"ZZZZ"; var[900:901] = b""; var = bytes(var)
+    for c, d in ((var, text[:2500]), (text[600:1800], text[:2500]), (text[:300], bytes(200)), (b"abc", b"abcabc"),
+                 (rng.integers(0, 256, 500, dtype=np.uint8).tobytes(), text[:700])):
+        for kw in (dict(), dict(chain_depth=3), dict(chain_depth=200)):
+            cfg = orc.default_cfg(**kw)
+            want, got = orc.deflate(c, cfg, d), pyref.deflate(c, d, chain_depth=kw.get("chain_depth", 0))
+            assert want == got, (len(c), len(d), kw)
+            assert _rt(got, d) == c
+    ml, md = orc.deflate_matches(text[:2500].encode() if isinstance(text, str) else text[:2500], orc.default_cfg())
+    pl, pd = pyref.lz_matches(text[:2500], b"", 32)
+    assert ml.tolist() == pl and md.tolist() == pd
 
 
 # ---------------------------------------------------------------- committed fixtures
