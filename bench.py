@@ -301,6 +301,21 @@ def main():
             if n.value:
                 read_info[nm] = round(ms.value / n.value, 3)
 
+    # the product's output: the shard's manifest records, packed on the GPU (outside the timed region, reported beside it)
+    manifest_info = None
+    if res.streams is not None and os.environ.get("HMSE_BENCH_NO_MANIFEST") != "1":
+        from hmse_amd import manifest
+        sb = res.shard_bases
+        manifest.pack_manifest_device(res, rank, world if sb else 1)   # warm-up (allocator, first launch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        unit, blob, index, cmap, ptrs = manifest.pack_manifest_device(res, rank, world if sb else 1)
+        torch.cuda.synchronize()
+        t_pack = time.perf_counter() - t0
+        manifest_info = {"pack_ms": round(t_pack * 1e3, 2), "blob_bytes": int(blob.numel()), "index_entries": int(index.shape[0]),
+                         "map_entries": int(cmap.shape[0]), "pointer_records": int(ptrs.shape[0]), "lba_unit": unit,
+                         "scope": "hmse_manifest_pack + record/pointer prefix sums, records resident in HBM when the clock stops (rank 0)"}
+        del blob, index, cmap, ptrs
     stats = [st]
     if distributed:
         allst = [None] * world
@@ -342,6 +357,9 @@ def main():
                                "valu_issue": valu_issue_note(),
                                "note": "`kernel` = the longest single launch, `dominant_stage` = the longest group of launches; both are "
                                        "integer-VALU/LDS-bound and priced against the HBM roof (SURVEY.md §8d); rank 0" + VALU_NOTE.get(dom, "")}
+        if manifest_info:
+            out["manifest"] = manifest_info
+            out["manifest_inclusive_GiB_per_s"] = round(tot["bytes"] / (dt / a.steps + manifest_info["pack_ms"] * 1e-3) / 2**30, 3)
         out["stage_roofline"] = stage_roof
         if read_info:
             out["read_path"] = read_info

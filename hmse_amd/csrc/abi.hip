@@ -8,6 +8,7 @@ size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l4_lsh_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
 size_t hmse_l1_inflate_workspace_bytes_impl(uint64_t n_chunks);
+size_t hmse_manifest_pack_workspace_bytes_impl(uint64_t n_chunks);
 
 extern "C" void hmse_cfg_default(hmse_cfg* c) {
   memset(c, 0, sizeof *c);
@@ -91,6 +92,7 @@ extern "C" size_t hmse_workspace_bytes(int stage, uint64_t n, const hmse_cfg* cf
     case HMSE_STAGE_L1_DEFLATE: return hmse_l1_deflate_workspace_bytes_impl(n, cfg);
     case HMSE_STAGE_L1_INFLATE: return hmse_l1_inflate_workspace_bytes_impl(n);
     case HMSE_STAGE_READ_ASSEMBLE: return 256;
+    case HMSE_STAGE_MANIFEST_PACK: return hmse_manifest_pack_workspace_bytes_impl(n);
     default: return 0;
   }
 }

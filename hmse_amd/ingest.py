@@ -35,6 +35,7 @@ class ShardResult:
     stream_off: torch.Tensor | None    # int64 [u+1]
     kind: torch.Tensor | None          # uint8 [u] FULL / DELTA
     stats: dict = field(default_factory=dict)
+    shard_bases: list | None = None    # sharded runs: chunk_base of every shard (what the manifest needs to name a target shard)
 
 
 def fixed_cuts(n: int, cfg: IngestConfig, seg_off: torch.Tensor) -> torch.Tensor:
@@ -49,7 +50,7 @@ def fixed_cuts(n: int, cfg: IngestConfig, seg_off: torch.Tensor) -> torch.Tensor
 def gather_digests(digests: torch.Tensor, group=None):
     """The one data-path collective: all-gather of (count, digests) over RCCL/xGMI.
 
-    Returns (all_digests [N, 32] in (rank, local) order, chunk_base of this rank, N)."""
+    Returns (all_digests [N, 32] in (rank, local) order, chunk_base of this rank, N, chunk_base of every rank)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -67,26 +68,34 @@ def gather_digests(digests: torch.Tensor, group=None):
         alld = allp
     else:
         alld = torch.cat([allp[r * mx: r * mx + cl[r]] for r in range(world)])
-    return alld, sum(cl[:rank]), sum(cl)
+    bases = [sum(cl[:r]) for r in range(world)]
+    return alld, bases[rank], sum(cl), bases
 
 
 def ingest_shard(data: torch.Tensor, cfg: IngestConfig, seg_off: torch.Tensor | None = None, group=None,
-                 distributed: bool = False, want_stats: bool = True) -> ShardResult:
-    """Run the enabled layers over this rank's shard (device-resident uint8 tensor)."""
+                 distributed: bool = False, want_stats: bool = True, exchange=None, pre=None) -> ShardResult:
+    """Run the enabled layers over this rank's shard (device-resident uint8 tensor).
+
+    `exchange(digests) -> (all_digests, chunk_base, n_global, shard_bases)` replaces the RCCL all-gather (used to run the
+    shards of a sharded store one after another on a single GPU); `pre = (cuts, digests)` skips L2/L3 when the caller has
+    already run them for that exchange."""
     n = data.numel()
     dev = data.device
     if seg_off is None:
         seg_off = ops.segment_offsets(n, cfg.seg_size, dev)
     # L2
-    cuts = ops.l2_cdc(data, cfg, seg_off) if cfg.layers & LAYER_L2 else fixed_cuts(n, cfg, seg_off)
+    if pre is not None:
+        cuts = pre[0]
+    else:
+        cuts = ops.l2_cdc(data, cfg, seg_off) if cfg.layers & LAYER_L2 else fixed_cuts(n, cfg, seg_off)
     n_chunks = cuts.numel() - 1
     digests = first_occ = refcount = None
-    chunk_base, n_global = 0, n_chunks
+    chunk_base, n_global, shard_bases = 0, n_chunks, None
     # L3
     if cfg.layers & LAYER_L3:
-        digests = ops.l3_sha256(data, cuts)
-        if distributed:
-            alld, chunk_base, n_global = gather_digests(digests, group)
+        digests = pre[1] if pre is not None else ops.l3_sha256(data, cuts)
+        if distributed or exchange is not None:
+            alld, chunk_base, n_global, shard_bases = (exchange or (lambda d: gather_digests(d, group)))(digests)
             fo_all, rc_all = ops.l3_dedup(alld)
             first_occ = fo_all[chunk_base: chunk_base + n_chunks]
             refcount = rc_all[chunk_base: chunk_base + n_chunks]
@@ -106,10 +115,27 @@ def ingest_shard(data: torch.Tensor, cfg: IngestConfig, seg_off: torch.Tensor | 
     if cfg.layers & LAYER_L1:
         streams, stream_off, kind = ops.l1_deflate(data, cuts, cfg, uniq_ids, base)
     res = ShardResult(n, cuts, digests, chunk_base, n_global, first_occ, refcount, uniq_ids, sig, band_keys, base,
-                      streams, stream_off, kind)
+                      streams, stream_off, kind, shard_bases=shard_bases)
     if want_stats:
         res.stats = shard_stats(res)
     return res
+
+
+def ingest_shards_local(shards: list, cfg: IngestConfig) -> list:
+    """A sharded ingest with every shard on THIS GPU, one after the other: L2/L3 of every shard first, then the digest
+    exchange as the all-gather would deliver it (concatenation in shard order), then L4/L1 per shard.  Each result is what
+    the rank that owns the shard would hold after ingest_shard(distributed=True) — used to build and verify a multi-shard
+    store without a second GPU, and by a single process that drives several shards."""
+    pre = []
+    for d in shards:
+        cuts = ops.l2_cdc(d, cfg) if cfg.layers & LAYER_L2 else fixed_cuts(d.numel(), cfg, ops.segment_offsets(d.numel(), cfg.seg_size, d.device))
+        pre.append((cuts, ops.l3_sha256(d, cuts) if cfg.layers & LAYER_L3 else None))
+    if not cfg.layers & LAYER_L3:
+        return [ingest_shard(d, cfg, pre=p) for d, p in zip(shards, pre)]
+    counts = [p[0].numel() - 1 for p in pre]
+    bases = [sum(counts[:r]) for r in range(len(shards))]
+    alld = torch.cat([p[1] for p in pre])
+    return [ingest_shard(d, cfg, pre=p, exchange=lambda _dg, r=r: (alld, bases[r], sum(counts), bases)) for r, (d, p) in enumerate(zip(shards, pre))]
 
 
 def shard_stats(r: ShardResult) -> dict:

@@ -1,4 +1,4 @@
-"""Chunk manifest: the reference's packed on-disk records, written by the host from a ShardResult.
+"""Chunk manifest: the reference's packed on-disk records, packed on the GPU from a ShardResult (hmse_manifest_pack).
 
 Layouts (little-endian, packed) exactly as in the reference:
   ChunkIndex  40 B {sha256[32], lba u32, length u16, refcount u16}        README.md:1263-1270, 2646-2651
@@ -6,8 +6,9 @@ Layouts (little-endian, packed) exactly as in the reference:
   pointer      8 B {target_lba u32, target_length u16, flags u16}          README.md:1312 ("LBA + offset")
 `lba` is a byte offset into the blob divided by `lba_unit` (the reference's LBA is a 512-byte SD
 sector; the unit is stored in the header and every record in the blob is aligned to it).
-The per-chunk map (README.md:1448 "Chunk Map [#301, #302d, ...]") is a u32 index-table slot plus a
-type tag per chunk.  `reconstruct()` is the three-branch read path of README.md:1621-1675, used
+The per-chunk map (README.md:1448 "Chunk Map [#301, #302d, ...]") is a u32 index-table slot, a type
+tag and the shard that holds the slot.  A sharded run (one process per GPU) writes one Manifest per
+shard; merge_manifests() resolves the pointers that cross shards into a Store.  `reconstruct()` is the three-branch read path of README.md:1621-1675, used
 as the end-to-end verifier (VALIDATION_METHODS.md:257 "100 % lossless reconstruction required").
 """
 from __future__ import annotations
@@ -25,110 +26,164 @@ MAGIC = b"HMSEMI35"
 CHUNK_INDEX_DTYPE = np.dtype([("sha256", "u1", 32), ("lba", "<u4"), ("length", "<u2"), ("refcount", "<u2")])
 DELTA_HDR_DTYPE = np.dtype([("base_lba", "<u4"), ("base_length", "<u2"), ("delta_length", "<u2")])
 POINTER_DTYPE = np.dtype([("target_lba", "<u4"), ("target_length", "<u2"), ("flags", "<u2")])
-MAP_DTYPE = np.dtype([("slot", "<u4"), ("raw_length", "<u2"), ("kind", "u1"), ("pad", "u1")])
+MAP_DTYPE = np.dtype([("slot", "<u4"), ("raw_length", "<u2"), ("kind", "u1"), ("shard", "u1")])
 assert CHUNK_INDEX_DTYPE.itemsize == 40 and DELTA_HDR_DTYPE.itemsize == 8 and POINTER_DTYPE.itemsize == 8
 
 
 @dataclass
 class Manifest:
+    """One shard's part of a store: its blob, its index, the map of ITS chunks (global chunk order = shard, local)."""
     lba_unit: int
     index: np.ndarray      # CHUNK_INDEX_DTYPE [n_unique]
     chunk_map: np.ndarray  # MAP_DTYPE [n_chunks]
     pointers: np.ndarray   # POINTER_DTYPE [n_pointer]
     blob: np.ndarray       # uint8: FULL streams and DeltaChunk records, lba_unit-aligned
+    shard: int = 0
+    n_shards: int = 1
+    chunk_base: int = 0    # global index of this shard's chunk 0
 
     def to_bytes(self) -> bytes:
-        hdr = MAGIC + struct.pack("<IIQQQQ", 1, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size)
+        hdr = MAGIC + struct.pack("<IIQQQQIIQ", 2, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size,
+                                  self.shard, self.n_shards, self.chunk_base)
         return hdr + self.index.tobytes() + self.chunk_map.tobytes() + self.pointers.tobytes() + self.blob.tobytes()
 
     @staticmethod
     def from_bytes(b: bytes) -> "Manifest":
         assert b[:8] == MAGIC
-        ver, unit, nu, nc, npt, nb = struct.unpack_from("<IIQQQQ", b, 8)
-        assert ver == 1
-        o = 8 + struct.calcsize("<IIQQQQ")
+        ver, unit, nu, nc, npt, nb, shard, n_shards, cbase = struct.unpack_from("<IIQQQQIIQ", b, 8)
+        assert ver == 2
+        o = 8 + struct.calcsize("<IIQQQQIIQ")
         idx = np.frombuffer(b, CHUNK_INDEX_DTYPE, nu, o); o += nu * 40
         cmap = np.frombuffer(b, MAP_DTYPE, nc, o); o += nc * 8
         ptr = np.frombuffer(b, POINTER_DTYPE, npt, o); o += npt * 8
         blob = np.frombuffer(b, np.uint8, nb, o)
-        return Manifest(unit, idx, cmap, ptr, blob)
+        return Manifest(unit, idx, cmap, ptr, blob, shard, n_shards, cbase)
+
+    def nbytes(self) -> int:
+        return 8 + struct.calcsize("<IIQQQQIIQ") + self.index.nbytes + self.chunk_map.nbytes + self.pointers.nbytes + self.blob.nbytes
 
 
-def build_manifest(res, first_occ_local: np.ndarray | None = None) -> Manifest:
-    """Host-side writer for a single-shard ShardResult (all chunks and their first occurrences local)."""
-    cuts = res.cuts.cpu().numpy().astype(np.int64)
-    n = len(cuts) - 1
-    lens = np.diff(cuts)
-    uniq = res.uniq_ids.cpu().numpy()
-    u = len(uniq)
-    off = res.stream_off.cpu().numpy().astype(np.int64)
-    kind_u = res.kind.cpu().numpy()
-    base = res.base.cpu().numpy() if res.base is not None else np.full(u, -1, np.int64)
-    streams = res.streams.cpu().numpy()
-    slen = np.diff(off)
-    rec_len = slen + np.where(kind_u == KIND_DELTA, 8, 0)
-    total = int(rec_len.sum())
+PTR_UNRESOLVED = 0x8000   # pointer-record flag: the target lives on another shard and its lba is filled in by merge_manifests
+
+
+def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
+    """The shard's packed records in HBM: (lba_unit, blob u8[], index u8[u,40], chunk_map u8[n,8], pointers u8[p,8]).
+    ONE pass of GPU kernels over the ShardResult (hmse_manifest_pack, hmse_amd/csrc/manifest_pack.hip) plus two prefix
+    sums for the record and pointer positions; the only host sync reads the two output sizes."""
+    import torch
+
+    from . import ops
+    if not res.cuts.is_cuda:
+        raise ops.HmseError(-1, "the manifest is packed on the GPU: the ShardResult must live in HBM")
+    if res.streams is None:
+        raise ops.HmseError(-1, "the manifest needs the L1 layer's streams")
+    dev = res.cuts.device
+    n = res.cuts.numel() - 1
+    u = res.uniq_ids.numel()
+    slen = res.stream_off[1:] - res.stream_off[:-1]
+    rec_len = slen + 8 * (res.kind == KIND_DELTA).to(torch.int64)
+    mine = torch.arange(res.chunk_base, res.chunk_base + n, dtype=torch.int64, device=dev)
+    is_ptr = (res.first_occ != mine) if res.first_occ is not None else torch.zeros(n, dtype=torch.bool, device=dev)
+    ptr_index = torch.cumsum(is_ptr.to(torch.int64), 0) - is_ptr.to(torch.int64)
+    total, n_ptr = (int(v) for v in torch.stack([rec_len.sum(), is_ptr.sum()]).tolist())   # the one host sync: sizes of the outputs
     unit = 1
-    while (total + unit * u) // unit >= 2**32:
+    while (total + unit * u) // unit >= 2**32:   # lba is 32 bits (README.md:1266): coarser units for blobs beyond 4 GiB
         unit *= 2
-    rec_off = np.zeros(u + 1, np.int64)
-    np.cumsum((rec_len + unit - 1) // unit * unit, out=rec_off[1:])
-    blob = np.zeros(int(rec_off[-1]), np.uint8)
-    index = np.zeros(u, CHUNK_INDEX_DTYPE)
-    dg = res.digests.cpu().numpy() if res.digests is not None else None
-    rc = res.refcount.cpu().numpy() if res.refcount is not None else None
-    index["lba"] = rec_off[:-1] // unit
-    index["length"] = rec_len
-    if dg is not None:
-        index["sha256"] = dg[uniq]
-        index["refcount"] = np.minimum(rc[uniq], 65535)
-    else:
-        index["refcount"] = 1
-    for k in range(u):  # host packing loop (not the hot path)
-        o = int(rec_off[k])
-        s = streams[off[k]:off[k + 1]]
-        if kind_u[k] == KIND_DELTA:
-            b = int(base[k])
-            hdr = np.zeros(1, DELTA_HDR_DTYPE)
-            hdr["base_lba"] = index["lba"][b]; hdr["base_length"] = index["length"][b]; hdr["delta_length"] = len(s)
-            blob[o:o + 8] = np.frombuffer(hdr.tobytes(), np.uint8)
-            o += 8
-        blob[o:o + len(s)] = s
-    cmap = np.zeros(n, MAP_DTYPE)
-    cmap["raw_length"] = np.minimum(lens, 65535)
-    slot_of = np.full(n, -1, np.int64)
-    slot_of[uniq] = np.arange(u)
-    if res.first_occ is not None:
-        fo = res.first_occ.cpu().numpy() - res.chunk_base
-        assert (fo >= 0).all() and (fo < n).all(), "build_manifest needs every first occurrence in this shard"
-    else:
-        fo = np.arange(n)
-    cmap["slot"] = slot_of[fo]
-    is_ptr = fo != np.arange(n)
-    cmap["kind"] = np.where(is_ptr, KIND_POINTER, kind_u[slot_of[fo]])
-    ptr = np.zeros(int(is_ptr.sum()), POINTER_DTYPE)
-    tgt = slot_of[fo[is_ptr]]
-    ptr["target_lba"] = index["lba"][tgt]; ptr["target_length"] = index["length"][tgt]; ptr["flags"] = KIND_POINTER
-    return Manifest(unit, index, cmap, ptr, blob)
+    rec_off = torch.zeros(u + 1, dtype=torch.int64, device=dev)
+    torch.cumsum((rec_len + (unit - 1)) // unit * unit, 0, out=rec_off[1:])
+    blob_bytes = total if unit == 1 else int(rec_off[-1].item())
+    blob = torch.empty(blob_bytes, dtype=torch.uint8, device=dev)
+    index = torch.empty((u, 40), dtype=torch.uint8, device=dev)
+    cmap = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+    ptrs = torch.empty((n_ptr, 8), dtype=torch.uint8, device=dev)
+    ops.manifest_pack(res, shard, n_shards, getattr(res, "shard_bases", None), rec_off, unit, ptr_index, blob, index, cmap, ptrs)
+    return unit, blob, index, cmap, ptrs
 
 
-def reconstruct(m: Manifest) -> bytes:
-    """Read path (README.md:1621-1675): FULL -> inflate; POINTER -> target; DELTA -> inflate with zdict=base."""
-    by_lba = {int(e["lba"]): i for i, e in enumerate(m.index)}
-    slot_kind = np.zeros(len(m.index), np.uint8)
-    own = m.chunk_map["kind"] != KIND_POINTER
-    slot_kind[m.chunk_map["slot"][own]] = m.chunk_map["kind"][own]
-    cache: dict[int, bytes] = {}
+def build_manifest(res, shard: int = 0, n_shards: int = 1) -> Manifest:
+    """pack_manifest_device() + one device -> host copy per array: the host receives four finished arrays and only has to
+    write() them.  A chunk whose first occurrence lives on another shard (sharded ingest) becomes a POINTER
+    with an unresolved pointer record; merge_manifests() resolves those once every shard's manifest exists."""
+    unit, blob, index, cmap, ptrs = pack_manifest_device(res, shard, n_shards)
+    host = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)
+    return Manifest(unit, host(index, CHUNK_INDEX_DTYPE), host(cmap, MAP_DTYPE), host(ptrs, POINTER_DTYPE), blob.cpu().numpy(),
+                    shard, n_shards, int(res.chunk_base))
 
-    def raw_of(slot: int) -> bytes:
-        if slot in cache:
-            return cache[slot]
-        e = m.index[slot]
-        o = int(e["lba"]) * m.lba_unit
-        rec = m.blob[o:o + int(e["length"])].tobytes()
-        if slot_kind[slot] == KIND_DELTA:  # DeltaChunk record: 8-byte header, then a stream with the base as dictionary
+
+@dataclass
+class Store:
+    """A sharded store: one Manifest per shard, cross-shard pointers resolved (global chunk order = shard, local index)."""
+    shards: list
+
+    def to_bytes(self) -> bytes:
+        parts = [m.to_bytes() for m in self.shards]
+        return b"HMSESTOR" + struct.pack("<I", len(parts)) + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+
+    @staticmethod
+    def from_bytes(b: bytes) -> "Store":
+        assert b[:8] == b"HMSESTOR"
+        (k,) = struct.unpack_from("<I", b, 8)
+        o, shards = 12, []
+        for _ in range(k):
+            (ln,) = struct.unpack_from("<Q", b, o)
+            shards.append(Manifest.from_bytes(b[o + 8:o + 8 + ln])); o += 8 + ln
+        return Store(shards)
+
+
+def merge_manifests(parts: list) -> Store:
+    """The global index of a sharded run: per-shard blobs and indexes stay as written; every POINTER whose target lives on
+    another shard gets its map slot (that shard's index slot) and its pointer record {target_lba, target_length,
+    flags = POINTER | shard << 4} from the target shard's own records (README.md:1312 "LBA + offset", 1635-1669)."""
+    parts = sorted(parts, key=lambda m: m.shard)
+    assert [m.shard for m in parts] == list(range(len(parts))) and all(m.n_shards == len(parts) for m in parts), "one manifest per shard"
+    out = []
+    for m in parts:
+        cmap, ptrs = m.chunk_map.copy(), m.pointers.copy()
+        is_ptr = cmap["kind"] == KIND_POINTER
+        unresolved = (ptrs["flags"] & PTR_UNRESOLVED) != 0
+        pidx = np.nonzero(is_ptr)[0][unresolved]                     # chunk index of every unresolved pointer
+        for r in np.unique(cmap["shard"][pidx]):
+            t = parts[int(r)]
+            assert int(r) < m.shard, "dedupe only ever points backwards"
+            sel = pidx[cmap["shard"][pidx] == r]
+            tgt_chunk = cmap["slot"][sel].astype(np.int64)           # the target shard's LOCAL chunk index
+            assert (tgt_chunk < len(t.chunk_map)).all() and (t.chunk_map["kind"][tgt_chunk] != KIND_POINTER).all(), \
+                "a cross-shard pointer must name a stored chunk of its target shard"
+            slot = t.chunk_map["slot"][tgt_chunk]
+            cmap["slot"][sel] = slot
+            rec = np.nonzero(unresolved)[0][cmap["shard"][pidx] == r]
+            ptrs["target_lba"][rec] = t.index["lba"][slot]
+            ptrs["target_length"][rec] = t.index["length"][slot]
+            ptrs["flags"][rec] = KIND_POINTER | (int(r) << 4)
+        out.append(Manifest(m.lba_unit, m.index, cmap, ptrs, m.blob, m.shard, m.n_shards, m.chunk_base))
+    return Store(out)
+
+
+def reconstruct(m) -> bytes:
+    """Read path (README.md:1621-1675) in plain Python + stock zlib — the end-to-end verifier: FULL -> inflate;
+    POINTER -> target (possibly on another shard); DELTA -> inflate with zdict = base.  Takes a Manifest or a Store."""
+    shards = m.shards if isinstance(m, Store) else [m]
+    if any(((s.pointers["flags"] & PTR_UNRESOLVED) != 0).any() for s in shards):
+        raise ValueError("the store has unresolved cross-shard pointers: merge_manifests() its shards first")
+    by_lba = [{int(e["lba"]): i for i, e in enumerate(s.index)} for s in shards]
+    slot_kind = []
+    for s in shards:
+        k = np.zeros(len(s.index), np.uint8)
+        own = s.chunk_map["kind"] != KIND_POINTER
+        k[s.chunk_map["slot"][own]] = s.chunk_map["kind"][own]
+        slot_kind.append(k)
+    cache: dict[tuple[int, int], bytes] = {}
+
+    def raw_of(r: int, slot: int) -> bytes:
+        if (r, slot) in cache:
+            return cache[(r, slot)]
+        s = shards[r]
+        e = s.index[slot]
+        o = int(e["lba"]) * s.lba_unit
+        rec = s.blob[o:o + int(e["length"])].tobytes()
+        if slot_kind[r][slot] == KIND_DELTA:  # DeltaChunk record: 8-byte header, then a stream with the base as dictionary
             base_lba, base_len, dlen = struct.unpack_from("<IHH", rec, 0)
-            d = zlib.decompressobj(-15, zdict=raw_of(by_lba[base_lba]))
+            d = zlib.decompressobj(-15, zdict=raw_of(r, by_lba[r][base_lba]))
             out = d.decompress(rec[8:8 + dlen]) + d.flush()
         else:
             d = zlib.decompressobj(-15)
@@ -136,7 +191,7 @@ def reconstruct(m: Manifest) -> bytes:
         assert d.eof and not d.unused_data
         if e["sha256"].any():
             assert hashlib.sha256(out).digest() == e["sha256"].tobytes(), "SHA-256 mismatch on reconstruct"
-        cache[slot] = out
+        cache[(r, slot)] = out
         return out
 
-    return b"".join(raw_of(int(s)) for s in m.chunk_map["slot"])
+    return b"".join(raw_of(int(c["shard"]), int(c["slot"])) for s in shards for c in s.chunk_map)

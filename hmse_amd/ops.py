@@ -15,7 +15,7 @@ from . import _lib
 from .config import IngestConfig
 
 STAGE_L2, STAGE_SHA, STAGE_DEDUP, STAGE_MINHASH, STAGE_LSH, STAGE_DEFLATE = 2, 3, 4, 5, 6, 7
-STAGE_INFLATE, STAGE_ASSEMBLE = 16, 17
+STAGE_INFLATE, STAGE_ASSEMBLE, STAGE_MANIFEST = 16, 17, 18
 
 
 class HmseError(RuntimeError):
@@ -247,3 +247,32 @@ def read_assemble(cuts: torch.Tensor, slot_of_chunk: torch.Tensor, raw_off: torc
     if int(status.item()):
         raise HmseError(-1, "hmse_read_assemble: chunk map disagrees with the stored lengths")
     return out
+
+
+def manifest_pack(res, shard: int, n_shards: int, shard_bases, rec_off: torch.Tensor, lba_unit: int, ptr_index: torch.Tensor,
+                  blob: torch.Tensor, index: torch.Tensor, chunk_map: torch.Tensor, pointers: torch.Tensor) -> None:
+    """hmse_manifest_pack over a ShardResult: blob, ChunkIndex table, chunk map and pointer records written in place.
+    README.md:1263-1270, 2182-2189, 1312, 1448."""
+    for t, nm in ((res.cuts, "cuts"), (res.uniq_ids, "uniq_ids"), (res.streams, "streams"), (res.stream_off, "stream_off"), (res.kind, "kind"),
+                  (rec_off, "rec_off"), (ptr_index, "ptr_index"), (blob, "blob"), (index, "index"), (chunk_map, "chunk_map"), (pointers, "pointers")):
+        _require_gpu(t, nm)
+    dev = res.cuts.device
+    n = res.cuts.numel() - 1
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _ws(workspace_bytes(STAGE_MANIFEST, n, IngestConfig()), dev)
+    base = res.base if res.base is not None else torch.full((res.uniq_ids.numel(),), -1, dtype=torch.int64, device=dev)
+    sb = None
+    if n_shards > 1:
+        sb = torch.as_tensor(list(shard_bases), dtype=torch.int64, device=dev)
+        if sb.numel() != n_shards:
+            raise HmseError(-1, "manifest_pack: one chunk base per shard")
+    keep = blob if blob.numel() else torch.empty(1, dtype=torch.uint8, device=dev)
+    rc = _lib.hip_lib().hmse_manifest_pack(_ptr(res.streams), _ptr(res.stream_off), _ptr(res.kind), _ptr(base), _ptr(res.uniq_ids),
+                                          res.uniq_ids.numel(), _ptr(res.digests), _ptr(res.refcount), _ptr(res.cuts), n, _ptr(res.first_occ),
+                                          int(res.chunk_base), shard, _ptr(sb), n_shards, _ptr(rec_off), lba_unit, _ptr(ptr_index), _ptr(keep),
+                                          blob.numel(), _ptr(index), _ptr(chunk_map), _ptr(pointers) if pointers.numel() else None,
+                                          pointers.shape[0], _ptr(status), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_manifest_pack")
+    st = int(status.item())
+    if st:
+        raise HmseError(-2, f"hmse_manifest_pack device status {st:#x}")

@@ -11,7 +11,7 @@ import torch
 
 from . import ops
 from .config import KIND_DELTA, KIND_POINTER
-from .manifest import Manifest
+from .manifest import Manifest, Store
 
 
 class ReadError(RuntimeError):
@@ -67,7 +67,7 @@ def parse_manifest(m: Manifest) -> dict:
     slot_kind = np.zeros(u, np.uint8)
     slot_kind[cmap["slot"][own]] = cmap["kind"][own]
     raw_len = np.zeros(u, np.int64)
-    raw_len[cmap["slot"]] = cmap["raw_length"]
+    raw_len[cmap["slot"][own]] = cmap["raw_length"][own]      # every stored slot is some local chunk's own record
     rec_off = idx["lba"].astype(np.int64) * m.lba_unit
     is_delta = slot_kind == KIND_DELTA
     s_off = rec_off + np.where(is_delta, 8, 0)
@@ -84,6 +84,37 @@ def parse_manifest(m: Manifest) -> dict:
         base[is_delta] = order[pos]
         s_len[is_delta] = hdr[:, 1] >> 16
     return {"kind": slot_kind, "base": base, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
+
+
+def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
+    """A sharded store (one Manifest per shard, cross-shard pointers resolved by manifest.merge_manifests) -> the
+    original corpus in global chunk order, decoded on `device`: every shard's records are inflated (a DELTA's dictionary
+    is always a chunk of the same shard), then ONE assembly pass lays out every chunk from the slot its map entry names —
+    its own shard's or, for a cross-shard POINTER, another's (README.md:1635-1669)."""
+    from .manifest import PTR_UNRESOLVED
+    if any(((m.pointers["flags"] & PTR_UNRESOLVED) != 0).any() for m in store.shards):
+        raise ReadError("the store has unresolved cross-shard pointers: merge_manifests() its shards first")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
+    raws, raw_offs, run = [], [], 0
+    for m in store.shards:
+        p = parse_manifest(m)
+        raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(p["stream_off"], torch.int64), t(p["kind"], torch.uint8), t(p["base"], torch.int64),
+                                         t(p["raw_len"], torch.int64), stream_len=t(p["stream_len"], torch.int32))
+        raws.append(raw); raw_offs.append(raw_off[:-1] + run); run += int(raw.numel())
+    raw_all = torch.cat(raws) if raws else torch.empty(0, dtype=torch.uint8, device=device)
+    raw_off_all = torch.cat(raw_offs + [torch.tensor([run], dtype=torch.int64, device=device)])
+    sb = np.cumsum([0] + [len(m.index) for m in store.shards])
+    slot_g = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in store.shards]) \
+        if store.shards else np.zeros(0, np.int64)
+    lens = np.concatenate([m.chunk_map["raw_length"].astype(np.int64) for m in store.shards]) if store.shards else np.zeros(0, np.int64)
+    cuts = torch.zeros(len(lens) + 1, dtype=torch.int64, device=device)
+    torch.cumsum(t(lens, torch.int64), 0, out=cuts[1:])
+    data = ops.read_assemble(cuts, t(slot_g, torch.int64), raw_off_all, raw_all)
+    if verify:
+        sha = np.concatenate([m.index["sha256"] for m in store.shards]) if store.shards else np.zeros((0, 32), np.uint8)
+        if len(sha) and sha.any():
+            verify_digests(data, cuts, t(sha[slot_g], torch.uint8))
+    return data
 
 
 def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:

@@ -45,7 +45,8 @@ enum {
   HMSE_STAGE_L1_DEFLATE = 7,
   /* read path; ids 8..15 are the DEFLATE kernels' profiling slots */
   HMSE_STAGE_L1_INFLATE    = 16,
-  HMSE_STAGE_READ_ASSEMBLE = 17
+  HMSE_STAGE_READ_ASSEMBLE = 17,
+  HMSE_STAGE_MANIFEST_PACK = 18
 };
 
 /* layer-enable mask == the reference's ablation matrix / degradation modes
@@ -225,6 +226,36 @@ int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, const uint64
 int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* slot_of_chunk, uint64_t n_slots,
                        const uint64_t* raw_off, const uint8_t* raw, uint8_t* data_out, uint64_t n,
                        uint32_t* status, void* stream);
+
+/*
+ * Chunk manifest — the packed on-disk records, written on the GPU (README.md:1263-1270 ChunkIndex 40 B, 2182-2189
+ * DeltaChunk 8-byte header + delta data, 1312 pointer 8 B, 1448 per-chunk map, 1635-1669 chunk types).  Replaces the
+ * reference's per-chunk "write chunk, insert (sha -> lba, len)" / "pointer record, refcount++" steps of the batch loop
+ * (README.md:1542-1551) by one pass over a whole shard; the host only write()s the four arrays.
+ *   streams/stream_off/kind/base/uniq_ids   the L1 outputs of the shard's n_unique stored chunks (base: slot index, -1 none)
+ *   digests DEVICE u8[n_chunks][32] or NULL, refcount DEVICE u32[n_chunks] or NULL, cuts DEVICE u64[n_chunks+1]
+ *   first_occ DEVICE u64[n_chunks] GLOBAL index of each chunk's first occurrence (NULL: every chunk is its own);
+ *             chunk_base = global index of this shard's chunk 0; shard / n_shards (<= 256); shard_bases DEVICE u64[n_shards]
+ *             = chunk_base of every shard (NULL when n_shards == 1)
+ *   rec_off   DEVICE u64[n_unique+1]: byte offset of each record in the blob (multiples of lba_unit, a power of two; the
+ *             record = 8-byte DeltaChunk header for DELTA + the stream); ptr_index DEVICE u64[n_chunks]: number of
+ *             POINTER chunks before chunk i
+ *   blob      DEVICE u8[blob_bytes]; index DEVICE 40 B x n_unique; chunk_map DEVICE 8 B x n_chunks
+ *             {slot u32, raw_length u16, kind u8, shard u8}; pointers DEVICE 8 B x n_pointers
+ *             {target_lba u32, target_length u16, flags u16 = HMSE_KIND_POINTER | shard << 4 | 0x8000 if unresolved}.
+ *             A chunk whose first occurrence lives on another shard gets slot = that shard's LOCAL chunk index and an
+ *             unresolved pointer record (target_lba 0xFFFFFFFF): the merge of the per-shard manifests fills them in.
+ *   status    DEVICE u32[1]: bit0 record does not fit (slot, 32-bit lba or 16-bit length), bit1 DELTA without an earlier
+ *             base, bit2 first occurrence is not a stored chunk, bit3 forward / unknown cross-shard target, bit4 pointer overflow
+ *   ws        hmse_workspace_bytes(HMSE_STAGE_MANIFEST_PACK, n_chunks, cfg)
+ */
+int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream_off, const uint8_t* kind, const int64_t* base,
+                       const uint64_t* uniq_ids, uint64_t n_unique, const uint8_t* digests, const uint32_t* refcount,
+                       const uint64_t* cuts, uint64_t n_chunks, const uint64_t* first_occ, uint64_t chunk_base,
+                       uint32_t shard, const uint64_t* shard_bases, uint32_t n_shards, const uint64_t* rec_off,
+                       uint32_t lba_unit, const uint64_t* ptr_index, uint8_t* blob, uint64_t blob_bytes, void* index,
+                       void* chunk_map, void* pointers, uint64_t n_pointers, uint32_t* status, void* ws, size_t ws_bytes,
+                       void* stream);
 
 /*
  * Diagnostics (bench.py's roofline leg): when enabled, every entry point brackets its DOMINANT

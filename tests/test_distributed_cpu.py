@@ -19,8 +19,8 @@ def _worker(rank, world, port, digests_by_rank, out_q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hmse_amd import ingest
-    alld, base, n = ingest.gather_digests(torch.from_numpy(digests_by_rank[rank]))
-    out_q.put((rank, alld.numpy().copy(), base, n))
+    alld, base, n, bases = ingest.gather_digests(torch.from_numpy(digests_by_rank[rank]))
+    out_q.put((rank, alld.numpy().copy(), base, n, bases))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,8 +50,8 @@ def test_gather_digests_and_global_dedup_two_ranks(orc):
         p.join(timeout=60)
         assert p.exitcode == 0
     ref_all = np.concatenate(dg)
-    for rank, alld, base, n in got:
-        assert n == len(ref_all) and base == (0 if rank == 0 else len(dg[0]))
+    for rank, alld, base, n, bases in got:
+        assert n == len(ref_all) and base == (0 if rank == 0 else len(dg[0])) and bases == [0, len(dg[0])]
         assert np.array_equal(alld, ref_all)                           # (rank, local) order, identical on every rank
     fo_sharded, rc_sharded = orc.dedup(ref_all)
     fo_single, rc_single = orc.dedup(orc.sha256_chunks(data, whole))

@@ -61,6 +61,9 @@ def test_full_pipeline_equals_oracle_and_reconstructs(orc, dev):
     assert res.stats["delta"] > 10 and res.stats["pointer"] > 10
     m = manifest.build_manifest(res)
     assert manifest.reconstruct(manifest.Manifest.from_bytes(m.to_bytes())) == data.tobytes()   # 100 % lossless (VALIDATION_METHODS.md:257)
+    # the GPU packer (hmse_manifest_pack) writes exactly the bytes of the host reference writer
+    import manifest_ref
+    assert manifest_ref.build(_to_host(res)).to_bytes() == m.to_bytes()
 
 
 @pytest.mark.parametrize("preset", ["l1_only", "l1_cdc", "l1_cdc_dedupe", "full", "l4_only", "cdc_dedupe"])
@@ -177,3 +180,69 @@ def test_incompressible_input_at_scale(dev):
         assert zlib.decompress(out[off[k]:off[k + 1]].tobytes(), -15) == host[cuts[k]:cuts[k + 1]].tobytes()
     st = ingest.merge_stats([res.stats])
     assert 0.98 < st["cf"] < 1.0
+
+
+def _to_host(res):
+    from hmse_amd import ingest
+    c = lambda t: None if t is None else t.cpu()
+    return ingest.ShardResult(res.n_bytes, c(res.cuts), c(res.digests), res.chunk_base, res.n_global, c(res.first_occ), c(res.refcount), c(res.uniq_ids),
+                              c(res.sig), c(res.band_keys), c(res.base), c(res.streams), c(res.stream_off), c(res.kind), shard_bases=res.shard_bases)
+
+
+def test_two_shard_store_on_one_gpu_merges_and_reads_back(orc, dev):
+    """BASELINE configs[3] as a complete product path, without a second GPU: two shards ingested one after the other with the
+    digest exchange an all-gather would deliver, one manifest per shard packed on the GPU, merged into a store whose
+    cross-shard POINTER records name (shard, lba) (README.md:1312, 1635-1669), read back on the GPU byte for byte; the
+    per-shard results equal the oracle's 2-shard pipeline and the packer equals the host reference writer."""
+    import torch
+    import manifest_ref
+    from hmse_amd import IngestConfig, corpus, ingest, manifest, read
+    from hmse_amd.config import KIND_POINTER
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(6 << 20, seed=42)
+    data[(4 << 20) + 5000:(5 << 20)] = data[5000:(1 << 20)]                       # cross-shard duplicates
+    shards, want = oracle_pipeline(orc, data, cfg, n_shards=2)
+    results = ingest.ingest_shards_local([torch.from_numpy(s).to(dev) for s in shards], cfg)
+    for r, (res, w) in enumerate(zip(results, want)):
+        assert res.chunk_base == w["chunk_base"] and res.shard_bases == [x["chunk_base"] for x in want]
+        assert np.array_equal(res.first_occ.cpu().numpy().astype(np.uint64), w["fo"])
+        assert np.array_equal(res.uniq_ids.cpu().numpy().astype(np.uint64), w["uniq"])
+        assert np.array_equal(res.streams.cpu().numpy(), w["out"]) and np.array_equal(res.kind.cpu().numpy(), w["kind"])
+    parts = [manifest.build_manifest(res, r, 2) for r, res in enumerate(results)]
+    for r, (res, m) in enumerate(zip(results, parts)):
+        assert manifest_ref.build(_to_host(res), r, 2).to_bytes() == m.to_bytes()
+    assert ((parts[1].pointers["flags"] & manifest.PTR_UNRESOLVED) != 0).sum() > 50
+    with pytest.raises(read.ReadError):
+        read.read_store(manifest.Store(parts), dev)
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    assert ((store.shards[1].chunk_map["kind"] == KIND_POINTER) & (store.shards[1].chunk_map["shard"] == 0)).sum() > 50
+    back = read.read_store(store, dev, verify=True)
+    assert torch.equal(back, torch.from_numpy(data).to(dev))
+    assert manifest.reconstruct(store) == data.tobytes()                          # and through stock zlib on the host
+    # a single-shard store reads back through the same entry point
+    one = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    assert torch.equal(read.read_store(manifest.merge_manifests([manifest.build_manifest(one)]), dev), torch.from_numpy(data).to(dev))
+
+
+def test_distributed_ingest_world_size_1_runs_rccl(dev):
+    """ingest_shard(distributed=True) under the driver: RCCL init, the count and digest all-gathers and the gathered dedupe
+    run at world size 1 and give the single-shard result (the N > 1 exchange itself is covered by the gloo tests)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from hmse_amd import IngestConfig, corpus, ingest, manifest, read
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = torch.from_numpy(corpus.wiki_synth(3 << 20, seed=42)).to(dev)
+    ref = ingest.ingest_shard(data, cfg)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        res = ingest.ingest_shard(data, cfg, distributed=True)
+    finally:
+        dist.destroy_process_group()
+    assert res.shard_bases == [0] and res.chunk_base == 0 and res.n_global == ref.cuts.numel() - 1
+    for a, b in ((res.first_occ, ref.first_occ), (res.uniq_ids, ref.uniq_ids), (res.base, ref.base), (res.streams, ref.streams), (res.kind, ref.kind)):
+        assert torch.equal(a, b)
+    assert torch.equal(read.read_store(manifest.merge_manifests([manifest.build_manifest(res, 0, 1)]), dev), data)

@@ -65,7 +65,8 @@ def test_manifest_records_and_reconstruct(orc):
     from hmse_amd.config import KIND_DELTA, KIND_POINTER
     data = variants_dataset(corpus.wiki_synth(3 << 20, seed=42))
     res = _shard_result_from_oracle(orc, data, {"seg_size": 1 << 20})
-    m = manifest.build_manifest(res)
+    import manifest_ref
+    m = manifest_ref.build(res)
     assert m.index.dtype.itemsize == 40 and m.pointers.dtype.itemsize == 8
     assert len(m.index) == res.stats["unique"] and len(m.pointers) == res.stats["pointer"] > 0
     assert (m.chunk_map["kind"] == KIND_DELTA).sum() == res.stats["delta"] > 0
@@ -139,7 +140,8 @@ def test_parse_manifest_matches_the_oracle_records(orc):
     from hmse_amd import corpus, manifest, read
     data = variants_dataset(corpus.wiki_synth(3 << 20, seed=42))
     res = _shard_result_from_oracle(orc, data, {"seg_size": 1 << 20})
-    m = manifest.Manifest.from_bytes(manifest.build_manifest(res).to_bytes())
+    import manifest_ref
+    m = manifest.Manifest.from_bytes(manifest_ref.build(res).to_bytes())
     p = read.parse_manifest(m)
     kind, base = res.kind.numpy(), res.base.numpy()
     off = res.stream_off.numpy()
@@ -176,3 +178,38 @@ def test_oracle_pool_equals_the_serial_oracle_pipeline(orc):
     assert (b["base"] >= 0).sum() > 10
     for k in ("cuts", "dg", "fo", "uniq", "sig", "base", "out", "off", "kind"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_two_shard_store_merges_and_reconstructs(orc):
+    """A sharded store: one manifest per shard, duplicates whose first occurrence lives on the other shard
+    become POINTERs that name (shard, lba) once merged (README.md:1312, 1635-1669); the stock-zlib verifier reads the whole
+    corpus back through them."""
+    import manifest_ref
+    from test_gpu_ingest import oracle_pipeline
+    from hmse_amd import IngestConfig, corpus, ingest, manifest
+    from hmse_amd.config import KIND_POINTER
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(6 << 20, seed=42)
+    data[(4 << 20) + 5000:(5 << 20)] = data[5000:(1 << 20)]                       # cross-shard duplicates
+    shards, want = oracle_pipeline(orc, data, cfg, n_shards=2)
+    t = torch.from_numpy
+    parts = []
+    bases = [w["chunk_base"] for w in want]
+    for r, w in enumerate(want):
+        n = len(w["cuts"]) - 1
+        res = ingest.ShardResult(shards[r].size, t(w["cuts"].astype(np.int64)), t(w["dg"]), w["chunk_base"], sum(len(x["cuts"]) - 1 for x in want),
+                                 t(w["fo"].astype(np.int64)), t(np.ones(n, np.int32)), t(w["uniq"].astype(np.int64)), None, None, t(w["base"]),
+                                 t(w["out"]), t(w["off"].astype(np.int64)), t(w["kind"]), shard_bases=bases)
+        parts.append(manifest_ref.build(res, r, 2))
+    cross = (parts[1].chunk_map["shard"] == 0).sum()
+    assert cross > 50 and ((parts[1].pointers["flags"] & manifest.PTR_UNRESOLVED) != 0).sum() == cross
+    with pytest.raises(Exception):
+        manifest.reconstruct(manifest.Store(parts))                               # unresolved pointers cannot be read
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    p1 = store.shards[1]
+    assert ((p1.pointers["flags"] & manifest.PTR_UNRESOLVED) == 0).all()
+    x = np.nonzero((p1.chunk_map["kind"] == KIND_POINTER) & (p1.chunk_map["shard"] == 0))[0]
+    ptr_of_chunk = np.cumsum(p1.chunk_map["kind"] == KIND_POINTER) - 1
+    rec = p1.pointers[ptr_of_chunk[x]]
+    assert np.array_equal(rec["target_lba"], store.shards[0].index["lba"][p1.chunk_map["slot"][x]]) and ((rec["flags"] >> 4) == 0).all()
+    assert manifest.reconstruct(store) == data.tobytes()
