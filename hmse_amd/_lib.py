@@ -66,6 +66,14 @@ def hip_lib():
         L.hmse_l3_sha256.argtypes = [_VP, _U64, _VP, _U64, _VP, _VP, _SZ, _VP]
         L.hmse_l3_dedup.restype = C.c_int
         L.hmse_l3_dedup.argtypes = [_VP, _U64, _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_l3_index_slots.restype = _U64
+        L.hmse_l3_index_slots.argtypes = [_U64]
+        L.hmse_l3_index_update.restype = C.c_int
+        L.hmse_l3_index_update.argtypes = [_VP, _U64, _U64, _VP, _VP, _VP, _U64, _VP]
+        L.hmse_l4_lsh_slots.restype = _U64
+        L.hmse_l4_lsh_slots.argtypes = [_U64]
+        L.hmse_l4_lsh_update.restype = C.c_int
+        L.hmse_l4_lsh_update.argtypes = [_VP, _U64, _U64, cfgp, _VP, _VP, _VP, _U64, _U32, _VP]
         L.hmse_l4_minhash.restype = C.c_int
         L.hmse_l4_minhash.argtypes = [_VP, _U64, _VP, _VP, _U64, cfgp, _VP, _VP, _SZ, _VP]
         L.hmse_l4_lsh.restype = C.c_int
@@ -104,5 +112,6 @@ def corpus_lib():
 
 EXPORTED_SYMBOLS = (
     "hmse_cfg_default", "hmse_cfg_validate", "hmse_abi_version", "hmse_strerror", "hmse_gear_table",
-    "hmse_workspace_bytes", "hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l4_minhash",
+    "hmse_workspace_bytes", "hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l3_index_slots", "hmse_l3_index_update",
+    "hmse_l4_lsh_slots", "hmse_l4_lsh_update", "hmse_l4_minhash",
     "hmse_l4_lsh", "hmse_l1_deflate", "hmse_l1_deflate_ex", "hmse_l1_deflate_record_bytes", "hmse_l1_inflate", "hmse_read_assemble", "hmse_manifest_pack", "hmse_profile_enable", "hmse_profile_read")

@@ -18,7 +18,10 @@ MAGIC = b"HMSEBAND"
 HDR_DTYPE = np.dtype([("band_hash", "<u2"), ("count", "<u2")])
 
 
-def write_band_tables(band_keys: np.ndarray, band_bits: int = 16) -> bytes:
+def write_band_tables(band_keys: np.ndarray, band_bits: int = 16, signatures: np.ndarray | None = None) -> bytes:
+    """Band tables in the reference's bucket-list layout; with `signatures` (u32[n][n_hashes]) a trailing section
+    "HMSESIGS" | u32 n_hashes | band keys u32[n][bands] | signatures u32[n][n_hashes] follows, from which a resumed ingest
+    rebuilds its content-addressed tables without recomputing a single MinHash (hmse_amd/stream.py resume)."""
     keys = np.ascontiguousarray(band_keys).view(np.uint32).reshape(band_keys.shape)
     n, bands = keys.shape
     if n >= 1 << 24:
@@ -45,7 +48,28 @@ def write_band_tables(band_keys: np.ndarray, band_bits: int = 16) -> bytes:
         id3 = np.zeros((n, 3), np.uint8)
         id3[:, 0] = ids & 0xFF; id3[:, 1] = (ids >> 8) & 0xFF; id3[:, 2] = (ids >> 16) & 0xFF
         out += [struct.pack("<Q", hdr.shape[0]), hdr.tobytes(), id3.tobytes()]
+    if signatures is not None:
+        sg = np.ascontiguousarray(signatures).view(np.uint32).reshape(signatures.shape)
+        assert sg.shape[0] == n
+        out += [b"HMSESIGS", struct.pack("<I", sg.shape[1]), keys.astype("<u4").tobytes(), sg.astype("<u4").tobytes()]
     return b"".join(out)
+
+
+def read_signatures(buf: bytes):
+    """-> (band keys u32[n][bands], signatures u32[n][n_hashes] or None) from the trailing section of write_band_tables()."""
+    assert buf[:8] == MAGIC
+    ver, bands, band_bits, id_bytes, n = struct.unpack_from("<IIIIQ", buf, 8)
+    o = 8 + struct.calcsize("<IIIIQ")
+    for _ in range(bands):
+        (nh,) = struct.unpack_from("<Q", buf, o)
+        o += 8 + 4 * nh + 3 * n
+    if buf[o:o + 8] != b"HMSESIGS":
+        return None, None
+    (nhash,) = struct.unpack_from("<I", buf, o + 8)
+    o += 12
+    keys = np.frombuffer(buf, "<u4", n * bands, o).reshape(n, bands); o += 4 * n * bands
+    sig = np.frombuffer(buf, "<u4", n * nhash, o).reshape(n, nhash)
+    return keys, sig
 
 
 def read_band_tables(buf: bytes):

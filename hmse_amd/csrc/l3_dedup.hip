@@ -27,11 +27,11 @@ __device__ __forceinline__ bool key_equal(const uint8_t* keys, size_t stride, ui
 // generic "first occurrence by key content" insert: keys[i] = KEY_U4*16 bytes at keys + stride*i
 template <int KEY_U4>
 __global__ __launch_bounds__(256) void fo_insert_kernel(const uint8_t* __restrict__ keys, size_t stride,
-                                                         const uint32_t* __restrict__ hashes, uint64_t n, uint32_t* table,
+                                                         const uint32_t* __restrict__ hashes, uint64_t i0, uint64_t n, uint32_t* table,
                                                          uint32_t mask) {
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
-  const uint32_t i = (uint32_t)i64;
+  const uint32_t i = (uint32_t)(i0 + i64);   // entries [i0, i0 + n) join a table that may already hold [0, i0)
   uint32_t hsh;
   if (hashes) hsh = hashes[i];
   else hsh = load_u32_unaligned(keys + stride * i);  // digests are uniform already
@@ -63,12 +63,12 @@ __device__ __forceinline__ uint32_t fo_lookup(const uint8_t* keys, size_t stride
   }
 }
 
-__global__ __launch_bounds__(256) void dedup_lookup_kernel(const uint8_t* __restrict__ digests, uint64_t n,
+__global__ __launch_bounds__(256) void dedup_lookup_kernel(const uint8_t* __restrict__ digests, uint64_t i0, uint64_t n,
                                                             const uint32_t* __restrict__ table, uint32_t mask,
                                                             uint64_t* __restrict__ first_occ, uint32_t* __restrict__ refcount) {
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
-  const uint32_t i = (uint32_t)i64;
+  const uint32_t i = (uint32_t)(i0 + i64);
   const uint32_t hsh = load_u32_unaligned(digests + 32 * (size_t)i);
   const uint32_t fo = fo_lookup<2>(digests, 32, hsh, i, table, mask);
   first_occ[i] = fo;
@@ -96,9 +96,33 @@ extern "C" int hmse_l3_dedup(const uint8_t* digests_all, uint64_t n_all, uint64_
   HMSE_HIP(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, stream));
   if (refcount) HMSE_HIP(hipMemsetAsync(refcount, 0, n_all * sizeof(uint32_t), stream));
   const uint32_t blocks = (uint32_t)((n_all + 255) / 256);
-  fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, n_all, table, slots - 1);
+  fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, 0, n_all, table, slots - 1);
   HMSE_LAUNCH_CHECK();
-  dedup_lookup_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, n_all, table, slots - 1, first_occ, refcount);
+  dedup_lookup_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 0, n_all, table, slots - 1, first_occ, refcount);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+// Persistent index (README.md:1288-1292 "lookup -> found: refcount++ / new: insert"): the table outlives the
+// call.  Digests [n_old, n_old + n_new) are inserted into a table that already holds [0, n_old), then looked up: a new chunk
+// equal to an old one finds the old index (smaller indices win the slot), so earlier first occurrences never change and a
+// batch costs O(n_new) whatever the history.
+extern "C" uint64_t hmse_l3_index_slots(uint64_t capacity_chunks) { return table_slots(capacity_chunks); }
+
+extern "C" int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, uint64_t n_new, uint64_t* first_occ,
+                                    uint32_t* refcount, uint32_t* table, uint64_t slots, void* stream_) {
+  if (!table || slots < 1024 || (slots & (slots - 1)) || slots > (1ull << 31)) return HMSE_EINVAL;
+  if (n_old + n_new >= 0x7FFFFFFFull || 2 * (n_old + n_new) > slots) return HMSE_ENOSPC;   // load factor <= 0.5
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  if (n_old == 0) HMSE_HIP(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, stream));
+  if (n_new == 0) return HMSE_OK;
+  if (!digests_all || !first_occ) return HMSE_EINVAL;
+  if (refcount) HMSE_HIP(hipMemsetAsync(refcount + n_old, 0, n_new * sizeof(uint32_t), stream));
+  const uint32_t blocks = (uint32_t)((n_new + 255) / 256);
+  fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, n_old, n_new, table, (uint32_t)(slots - 1));
+  HMSE_LAUNCH_CHECK();
+  dedup_lookup_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, n_old, n_new, table, (uint32_t)(slots - 1), first_occ, refcount);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

@@ -32,10 +32,11 @@ __device__ __forceinline__ uint32_t murmur3_words(const uint32_t* p, uint32_t nw
   return h;
 }
 
-__global__ __launch_bounds__(256) void lsh_keys_kernel(const uint32_t* __restrict__ sig, uint64_t n, uint32_t bands,
+__global__ __launch_bounds__(256) void lsh_keys_kernel(const uint32_t* __restrict__ sig, uint64_t i0, uint64_t n, uint32_t bands,
                                                         uint32_t rows, uint32_t* __restrict__ keys) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * bands) return;
+  g += i0 * bands;   // chunks [i0, i0 + n)
   const uint64_t i = g / bands;
   const uint32_t b = (uint32_t)(g % bands);
   keys[g] = murmur3_words(sig + i * (uint64_t)(bands * rows) + (uint64_t)b * rows, rows, b);
@@ -51,10 +52,11 @@ __device__ __forceinline__ bool band_equal(const uint32_t* sig, uint32_t nh, uin
 
 // one thread per (chunk, band): claim / lower the slot holding this band's content
 __global__ __launch_bounds__(256) void lsh_insert_kernel(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ keys,
-                                                          uint64_t n, uint32_t bands, uint32_t rows, uint32_t* tables,
+                                                          uint64_t i0, uint64_t n, uint32_t bands, uint32_t rows, uint32_t* tables,
                                                           uint32_t slots) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * bands) return;
+  g += i0 * bands;   // chunks [i0, i0 + n) join tables that may already hold [0, i0)
   const uint32_t i = (uint32_t)(g / bands), b = (uint32_t)(g % bands);
   uint32_t* table = tables + (uint64_t)b * slots;
   const uint32_t mask = slots - 1, nh = bands * rows;
@@ -75,12 +77,12 @@ __global__ __launch_bounds__(256) void lsh_insert_kernel(const uint32_t* __restr
 
 // one thread per chunk: earliest chunk sharing any whole band
 __global__ __launch_bounds__(256) void lsh_base_kernel(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ keys,
-                                                        uint64_t n, uint32_t bands, uint32_t rows,
+                                                        uint64_t i0, uint64_t n, uint32_t bands, uint32_t rows,
                                                         const uint32_t* __restrict__ tables, uint32_t slots,
                                                         int64_t* __restrict__ base) {
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
-  const uint32_t i = (uint32_t)i64, mask = slots - 1, nh = bands * rows;
+  const uint32_t i = (uint32_t)(i0 + i64), mask = slots - 1, nh = bands * rows;
   uint32_t best = LS_EMPTY;
   for (uint32_t b = 0; b < bands; b++) {
     const uint32_t* table = tables + (uint64_t)b * slots;
@@ -119,13 +121,46 @@ extern "C" int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* 
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   HMSE_HIP(hipMemsetAsync(ws, 0xFF, need, stream));
   const uint64_t nb = n_sel * cfg->bands;
-  lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, n_sel, cfg->bands, cfg->rows, band_keys);
+  lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, 0, n_sel, cfg->bands, cfg->rows, band_keys);
   HMSE_LAUNCH_CHECK();
-  lsh_insert_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, band_keys, n_sel, cfg->bands, cfg->rows,
+  lsh_insert_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, band_keys, 0, n_sel, cfg->bands, cfg->rows,
                                                                                  (uint32_t*)ws, slots);
   HMSE_LAUNCH_CHECK();
-  lsh_base_kernel<<<dim3((uint32_t)((n_sel + 255) / 256)), dim3(256), 0, stream>>>(sig, band_keys, n_sel, cfg->bands, cfg->rows,
+  lsh_base_kernel<<<dim3((uint32_t)((n_sel + 255) / 256)), dim3(256), 0, stream>>>(sig, band_keys, 0, n_sel, cfg->bands, cfg->rows,
                                                                                    (const uint32_t*)ws, slots, base);
   HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+// Persistent band tables (README.md:1554-1576 "probe LSH ... insert signature"): chunks
+// [n_old, n_old + n_new) of the signature array join tables that already hold [0, n_old); base[] of the new chunks is the
+// earliest chunk (old or new) sharing a whole band.  Smaller indices win a slot, so the bases of earlier chunks never
+// change and a batch costs O(n_new).  With keys_given != 0 the band keys of the new chunks are already in band_keys (loaded
+// from a stored band table) and are not recomputed.
+extern "C" uint64_t hmse_l4_lsh_slots(uint64_t capacity_chunks) { return lsh_slots(capacity_chunks); }
+
+extern "C" int hmse_l4_lsh_update(const uint32_t* sig_all, uint64_t n_old, uint64_t n_new, const hmse_cfg* cfg, uint32_t* band_keys,
+                                  int64_t* base, uint32_t* tables, uint64_t slots, uint32_t keys_given, void* stream_) {
+  if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
+  if (!tables || slots < 1024 || (slots & (slots - 1)) || slots > (1ull << 24)) return HMSE_EINVAL;
+  if (2 * (n_old + n_new) > slots) return HMSE_ENOSPC;   // load factor <= 0.5
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  if (n_old == 0) HMSE_HIP(hipMemsetAsync(tables, 0xFF, (size_t)slots * 4 * cfg->bands, stream));
+  if (n_new == 0) return HMSE_OK;
+  if (!sig_all || !band_keys) return HMSE_EINVAL;
+  const uint64_t nb = n_new * cfg->bands;
+  if (!keys_given) {
+    lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig_all, n_old, n_new, cfg->bands, cfg->rows, band_keys);
+    HMSE_LAUNCH_CHECK();
+  }
+  lsh_insert_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig_all, band_keys, n_old, n_new, cfg->bands, cfg->rows, tables,
+                                                                                 (uint32_t)slots);
+  HMSE_LAUNCH_CHECK();
+  if (base) {
+    lsh_base_kernel<<<dim3((uint32_t)((n_new + 255) / 256)), dim3(256), 0, stream>>>(sig_all, band_keys, n_old, n_new, cfg->bands, cfg->rows, tables,
+                                                                                     (uint32_t)slots, base);
+    HMSE_LAUNCH_CHECK();
+  }
   return HMSE_OK;
 }

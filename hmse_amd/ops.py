@@ -117,6 +117,40 @@ def l3_dedup(digests: torch.Tensor):
     return fo, rc_t
 
 
+def l3_index_slots(capacity_chunks: int) -> int:
+    return int(_lib.hip_lib().hmse_l3_index_slots(int(capacity_chunks)))
+
+
+def l3_index_update(digests_all: torch.Tensor, n_old: int, n_new: int, first_occ: torch.Tensor, refcount: torch.Tensor,
+                    table: torch.Tensor) -> None:
+    """Persistent L3 index: digests [n_old, n_old + n_new) join `table` (int32[l3_index_slots(capacity)], kept by the
+    caller across calls); first_occ / refcount tails are written in place.  README.md:1288-1292."""
+    for t, nm in ((digests_all, "digests"), (first_occ, "first_occ"), (refcount, "refcount"), (table, "table")):
+        _require_gpu(t, nm)
+    if digests_all.shape[0] < n_old + n_new or first_occ.numel() < n_old + n_new or refcount.numel() < n_old + n_new:
+        raise HmseError(-1, "l3_index_update: arrays shorter than n_old + n_new")
+    rc = _lib.hip_lib().hmse_l3_index_update(_ptr(digests_all), n_old, n_new, _ptr(first_occ), _ptr(refcount), _ptr(table), table.numel(), _stream())
+    _check(rc, "hmse_l3_index_update")
+
+
+def l4_lsh_slots(capacity_chunks: int) -> int:
+    return int(_lib.hip_lib().hmse_l4_lsh_slots(int(capacity_chunks)))
+
+
+def l4_lsh_update(sig_all: torch.Tensor, n_old: int, n_new: int, cfg: IngestConfig, band_keys: torch.Tensor, base: torch.Tensor | None,
+                  tables: torch.Tensor, keys_given: bool = False) -> None:
+    """Persistent L4b band tables: signatures [n_old, n_old + n_new) join `tables` (int32[bands, l4_lsh_slots(capacity)]);
+    band_keys / base tails are written in place.  README.md:1554-1576, 1937-1945."""
+    for t, nm in ((sig_all, "sig"), (band_keys, "band_keys"), (tables, "tables")):
+        _require_gpu(t, nm)
+    if sig_all.shape[0] < n_old + n_new or band_keys.shape[0] < n_old + n_new or (base is not None and base.numel() < n_old + n_new):
+        raise HmseError(-1, "l4_lsh_update: arrays shorter than n_old + n_new")
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_l4_lsh_update(_ptr(sig_all), n_old, n_new, C.byref(c), _ptr(band_keys), _ptr(base), _ptr(tables), tables.shape[1],
+                                          1 if keys_given else 0, _stream())
+    _check(rc, "hmse_l4_lsh_update")
+
+
 def l4_minhash(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None) -> torch.Tensor:
     """MinHash signatures -> int32 [n_sel, 128] (uint32 bits). README.md:2578-2598."""
     _require_gpu(data, "data")

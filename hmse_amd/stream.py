@@ -4,9 +4,10 @@ batch k+1 overlap the kernels of batch k, and the index persists across batches.
 Every batch runs the same C-ABI stages as ingest_shard; what persists between batches lives in HBM:
   * the raw bytes of everything ingested so far (288 GB of HBM hold the whole 4 x 10 GB configuration), so a chunk of
     an earlier batch can serve as DEFLATE dictionary for a later one (hmse_l1_deflate_ex, HMSE_DEFLATE_BASE_IS_CHUNK_ID);
-  * all cut points, digests (the L3 index of README.md:1263-1270 — first occurrences are GLOBAL over the stream),
-    signatures of the stored chunks (the L4 band tables are rebuilt from them; a base is the earliest stored chunk that
-    shares a band, whichever batch it came from).
+  * all cut points, digests and the L3 hash table over them (README.md:1263-1270, 1288-1292 — first occurrences are GLOBAL
+    over the stream), signatures of the stored chunks and the four L4 band tables (a base is the earliest stored chunk that
+    shares a band, whichever batch it came from).  Tables and arrays are allocated once and updated IN PLACE: a batch
+    inserts and looks up only its own chunks, so its cost does not grow with the history.
 With batches that are whole multiples of the segment size, every output equals what ingest_shard returns for the
 concatenated input, bit for bit (tests/test_gpu_stream.py) — batching is a schedule, not a different result.
 """
@@ -20,7 +21,7 @@ from .ingest import ShardResult, shard_stats
 
 
 class StreamIngest:
-    def __init__(self, cfg: IngestConfig, capacity_bytes: int, device):
+    def __init__(self, cfg: IngestConfig, capacity_bytes: int, device, max_chunks: int | None = None):
         if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
             raise ValueError("StreamIngest runs the full L1-L4 pipeline")
         self.cfg, self.dev = cfg, device
@@ -29,29 +30,63 @@ class StreamIngest:
         self.n_done = 0             # bytes processed
         self.copy_stream = torch.cuda.Stream(device=device)
         self.pending: list[tuple[int, int, torch.cuda.Event]] = []   # (offset, length, copy-done event)
-        z64 = lambda n: torch.zeros(n, dtype=torch.int64, device=device)
-        self.cuts = z64(1)
-        self.digests = torch.empty((0, 32), dtype=torch.uint8, device=device)
-        self.uniq_ids = z64(0)      # global chunk index of every stored chunk, ascending
-        self.sig = torch.empty((0, cfg.n_hashes), dtype=torch.int32, device=device)
-        self.base = z64(0)          # per stored chunk: slot of its dictionary chunk or -1
-        self.kind = torch.empty(0, dtype=torch.uint8, device=device)
-        self.stream_off = z64(1)
+        # The index persists in HBM across batches (README.md:1288-1292, 1554-1576): every per-chunk array is allocated
+        # once for `max_chunks` (default: twice the expected count at the configured average chunk size) and only its tail
+        # is written by a batch; the L3 table and the four L4 band tables are updated in place (hmse_l3_index_update,
+        # hmse_l4_lsh_update), so a batch costs the same whatever came before it.
+        self.max_chunks = int(max_chunks or (capacity_bytes // max(1, cfg.avg_size // 2) + capacity_bytes // cfg.seg_size + 64))
+        self.max_unique = min(self.max_chunks, 1 << 23)              # the band tables hold 2^24 slots at load <= 0.5
+        mc, mu = self.max_chunks, self.max_unique
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        self._cuts = z(mc + 1, torch.int64)
+        self._digests = torch.empty((mc, 32), dtype=torch.uint8, device=device)
+        self._first_occ = z(mc, torch.int64)
+        self._refcount = z(mc, torch.int32)
+        self._uniq = z(mu, torch.int64)         # global chunk index of every stored chunk, ascending
+        self._sig = torch.empty((mu, cfg.n_hashes), dtype=torch.int32, device=device)
+        self._band_keys = z((mu, cfg.bands), torch.int32)
+        self._base = z(mu, torch.int64)         # per stored chunk: slot of its dictionary chunk or -1
+        self._kind = z(mu, torch.uint8)
+        self._stream_off = z(mu + 1, torch.int64)
+        self._l3_table = torch.empty(ops.l3_index_slots(mc), dtype=torch.int32, device=device)
+        self._lsh_tables = torch.empty((cfg.bands, ops.l4_lsh_slots(mu)), dtype=torch.int32, device=device)
+        self.n_chunks = 0
+        self.n_unique = 0
+        self.stream_bytes = 0
         self.stream_parts: list[torch.Tensor] = []
-        self.first_occ = z64(0)
-        self.refcount = torch.empty(0, dtype=torch.int32, device=device)
-        self.band_keys = torch.empty((0, cfg.bands), dtype=torch.int32, device=device)
+
+    # views of the filled part of the index
+    cuts = property(lambda self: self._cuts[: self.n_chunks + 1])
+    digests = property(lambda self: self._digests[: self.n_chunks])
+    first_occ = property(lambda self: self._first_occ[: self.n_chunks])
+    refcount = property(lambda self: self._refcount[: self.n_chunks])
+    uniq_ids = property(lambda self: self._uniq[: self.n_unique])
+    sig = property(lambda self: self._sig[: self.n_unique])
+    band_keys = property(lambda self: self._band_keys[: self.n_unique])
+    base = property(lambda self: self._base[: self.n_unique])
+    kind = property(lambda self: self._kind[: self.n_unique])
+    stream_off = property(lambda self: self._stream_off[: self.n_unique + 1])
+
+    def index_sidecar(self) -> bytes:
+        """The L4 index for a later resume(): the reference's band tables (per band {band_hash u16, count u16} + 3-byte ids,
+        README.md:1937-1945) followed by the signatures, which the content-addressed tables in HBM are rebuilt from."""
+        from . import bandtable
+        return bandtable.write_band_tables(self.band_keys.cpu().numpy(), self.cfg.band_bits, signatures=self.sig.cpu().numpy())
 
     @staticmethod
-    def resume(m, cfg: IngestConfig, capacity_bytes: int, device) -> "StreamIngest":
-        """Incremental ingest against an existing store: the manifest is read back on the GPU (every record
-        inflated, every chunk's SHA-256 re-checked), which restores the raw bytes in HBM; cut points, digests and kinds come
-        from its records, signatures and bases are recomputed from the restored bytes.  Batches pushed afterwards dedupe and
-        delta against the restored chunks exactly as if the whole history had been one stream."""
+    def resume(m, cfg: IngestConfig, capacity_bytes: int, device, band_tables: bytes | None = None, verify: bool = True,
+               max_chunks: int | None = None) -> "StreamIngest":
+        """Incremental ingest against an existing store.  The raw bytes come back through the GPU read path
+        (any stored chunk may become a dictionary); the INDEX is loaded, not recomputed: digests from the ChunkIndex records
+        go straight into the L3 table, band keys and signatures from the band-table sidecar (index_sidecar()) go straight
+        into the L4 tables.  Without a sidecar the signatures are recomputed from the restored bytes.  `verify` re-checks
+        every chunk's SHA-256 while reading (the reference's read-side gate, README.md:1329).  Batches pushed afterwards
+        dedupe and delta against the restored chunks exactly as if the whole history had been one stream."""
         import numpy as np
-        from . import read
-        st = StreamIngest(cfg, capacity_bytes, device)
-        data = read.read_manifest(m, device, verify=True)
+        from . import bandtable, read
+        from .config import KIND_POINTER
+        st = StreamIngest(cfg, capacity_bytes, device, max_chunks)
+        data = read.read_manifest(m, device, verify=verify)
         n = data.numel()
         if n % cfg.seg_size:
             raise ValueError("the stored stream ends inside a segment: nothing can be appended to it")
@@ -60,25 +95,39 @@ class StreamIngest:
         st.data[:n] = data
         p = read.parse_manifest(m)
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
-        st.cuts = torch.zeros(len(m.chunk_map) + 1, dtype=torch.int64, device=device)
-        torch.cumsum(t(p["raw_len"][m.chunk_map["slot"]], torch.int64), 0, out=st.cuts[1:])
-        st.digests = t(m.index["sha256"][m.chunk_map["slot"]], torch.uint8)
-        st.first_occ, st.refcount = ops.l3_dedup(st.digests)
-        idx = torch.arange(st.first_occ.numel(), dtype=torch.int64, device=device)
-        st.uniq_ids = idx[st.first_occ == idx]
-        if st.uniq_ids.numel() != len(m.index):
+        nc, nu = len(m.chunk_map), len(m.index)
+        if nc > st.max_chunks or nu > st.max_unique:
+            raise ValueError("stream index capacity exceeded")
+        torch.cumsum(t(p["raw_len"][m.chunk_map["slot"]], torch.int64), 0, out=st._cuts[1: nc + 1])
+        st._digests[:nc] = t(m.index["sha256"][m.chunk_map["slot"]], torch.uint8)
+        ops.l3_index_update(st._digests, 0, nc, st._first_occ, st._refcount, st._l3_table)
+        own = np.nonzero(m.chunk_map["kind"] != KIND_POINTER)[0]
+        if len(own) != nu or not np.array_equal(m.chunk_map["slot"][own], np.arange(nu)):
             raise ValueError("manifest index and chunk map disagree on the stored chunks")
-        st.sig = ops.l4_minhash(st.data[:n], st.cuts, cfg, st.uniq_ids)
-        st.band_keys, st.base = ops.l4_lsh(st.sig, cfg)
-        st.kind = t(p["kind"], torch.uint8)
+        st._uniq[:nu] = t(own, torch.int64)
+        st.n_chunks, st.n_unique = nc, nu
+        idx = torch.arange(nc, dtype=torch.int64, device=device)
+        if not torch.equal(idx[st.first_occ == idx], st.uniq_ids):
+            raise ValueError("the stored chunks are not the first occurrences of their digests")
+        if band_tables is not None:
+            keys, sig = bandtable.read_signatures(band_tables)
+            if sig is None or sig.shape != (nu, cfg.n_hashes) or keys.shape != (nu, cfg.bands):
+                raise ValueError("the band-table sidecar does not belong to this manifest / configuration")
+            st._sig[:nu] = t(sig.view(np.int32), torch.int32)
+            st._band_keys[:nu] = t(keys.view(np.int32), torch.int32)
+            ops.l4_lsh_update(st._sig, 0, nu, cfg, st._band_keys, st._base, st._lsh_tables, keys_given=True)
+        else:
+            st._sig[:nu] = ops.l4_minhash(st.data[:n], st.cuts, cfg, st.uniq_ids)
+            ops.l4_lsh_update(st._sig, 0, nu, cfg, st._band_keys, st._base, st._lsh_tables)
+        st._kind[:nu] = t(p["kind"], torch.uint8)
         # dense copy of the stored streams (the blob aligns records to lba_unit and prefixes DELTA records with a header)
         s_len = t(p["stream_len"], torch.int64)
-        st.stream_off = torch.zeros(s_len.numel() + 1, dtype=torch.int64, device=device)
-        torch.cumsum(s_len, 0, out=st.stream_off[1:])
-        src = torch.arange(int(st.stream_off[-1].item()), dtype=torch.int64, device=device) + \
-            torch.repeat_interleave(t(p["stream_off"], torch.int64) - st.stream_off[:-1], s_len)
+        torch.cumsum(s_len, 0, out=st._stream_off[1: nu + 1])
+        st.stream_bytes = int(st._stream_off[nu].item())
+        src = torch.arange(st.stream_bytes, dtype=torch.int64, device=device) + \
+            torch.repeat_interleave(t(p["stream_off"], torch.int64) - st._stream_off[:nu], s_len)
         st.stream_parts = [t(m.blob, torch.uint8)[src]]
-        # the records must agree with what this build derives from the restored bytes
+        # the records must agree with what this build derives from the loaded index
         mb = t(p["base"], torch.int64)
         if not bool(((st.kind != 2) | (mb == st.base)).all()):
             raise ValueError("a DELTA record's dictionary is not the LSH base of its chunk under this configuration")
@@ -107,7 +156,7 @@ class StreamIngest:
         while self.pending:
             self._process(*self.pending.pop(0))
         streams = torch.cat(self.stream_parts) if self.stream_parts else torch.empty(0, dtype=torch.uint8, device=self.dev)
-        res = ShardResult(self.n_done, self.cuts, self.digests, 0, self.cuts.numel() - 1, self.first_occ, self.refcount, self.uniq_ids,
+        res = ShardResult(self.n_done, self.cuts, self.digests, 0, self.n_chunks, self.first_occ, self.refcount, self.uniq_ids,
                           self.sig, self.band_keys, self.base, streams, self.stream_off, self.kind)
         res.stats = shard_stats(res)
         return res
@@ -119,29 +168,32 @@ class StreamIngest:
         batch = self.data[off: off + n]
         all_data = self.data[: off + n]
         # L2 on the batch (segments restart at batch-local multiples of seg_size == global ones), offsets made global
-        cuts_b = ops.l2_cdc(batch, cfg) + off
-        n_old = self.cuts.numel() - 1
-        self.cuts = torch.cat([self.cuts, cuts_b[1:]])
-        n_new = cuts_b.numel() - 1
-        # L3: digests of the new chunks, first occurrences over the whole stream
-        dig_b = ops.l3_sha256(all_data, self.cuts[n_old:])
-        self.digests = torch.cat([self.digests, dig_b])
-        self.first_occ, self.refcount = ops.l3_dedup(self.digests)
+        cuts_b = ops.l2_cdc(batch, cfg)
+        n_old, n_new = self.n_chunks, cuts_b.numel() - 1
+        if n_old + n_new > self.max_chunks:
+            raise ValueError("stream index capacity exceeded (max_chunks)")
+        self._cuts[n_old + 1: n_old + n_new + 1] = cuts_b[1:] + off
+        cuts_all = self._cuts[: n_old + n_new + 1]
+        # L3: digests of the new chunks join the persistent table; first occurrences are global over the stream
+        self._digests[n_old: n_old + n_new] = ops.l3_sha256(all_data, self._cuts[n_old: n_old + n_new + 1])
+        ops.l3_index_update(self._digests, n_old, n_new, self._first_occ, self._refcount, self._l3_table)
         idx_new = torch.arange(n_old, n_old + n_new, dtype=torch.int64, device=dev)
-        uniq_new = idx_new[self.first_occ[n_old:] == idx_new]
-        u_old = self.uniq_ids.numel()
-        self.uniq_ids = torch.cat([self.uniq_ids, uniq_new])
-        # L4: signatures of the new stored chunks; bases over every stored chunk so far (earliest sharer wins, so the
-        # bases of earlier slots never change and only the tail is new)
-        sig_b = ops.l4_minhash(all_data, self.cuts, cfg, uniq_new)
-        self.sig = torch.cat([self.sig, sig_b])
-        self.band_keys, base_all = ops.l4_lsh(self.sig, cfg)
-        base_new = base_all[u_old:]
-        self.base = torch.cat([self.base, base_new])
+        uniq_new = idx_new[self._first_occ[n_old: n_old + n_new] == idx_new]
+        u_old, nu = self.n_unique, int(uniq_new.numel())
+        if u_old + nu > self.max_unique:
+            raise ValueError("stream index capacity exceeded (stored chunks)")
+        self._uniq[u_old: u_old + nu] = uniq_new
+        # L4: signatures of the new stored chunks join the persistent band tables; a base is the earliest stored chunk
+        # sharing a band, whichever batch it came from
+        self._sig[u_old: u_old + nu] = ops.l4_minhash(all_data, cuts_all, cfg, uniq_new)
+        ops.l4_lsh_update(self._sig, u_old, nu, cfg, self._band_keys, self._base, self._lsh_tables)
+        base_new = self._base[u_old: u_old + nu]
         # L1: the dictionary may be a chunk of an earlier batch -> bases as chunk indices
-        base_chunk = torch.where(base_new >= 0, self.uniq_ids[base_new.clamp(min=0)], base_new)
-        streams_b, off_b, kind_b = ops.l1_deflate(all_data, self.cuts, cfg, uniq_new, base_chunk, base_is_chunk_id=True)
+        base_chunk = torch.where(base_new >= 0, self._uniq[base_new.clamp(min=0)], base_new)
+        streams_b, off_b, kind_b = ops.l1_deflate(all_data, cuts_all, cfg, uniq_new, base_chunk, base_is_chunk_id=True)
         self.stream_parts.append(streams_b)
-        self.stream_off = torch.cat([self.stream_off, off_b[1:] + self.stream_off[-1]])
-        self.kind = torch.cat([self.kind, kind_b])
+        self._stream_off[u_old + 1: u_old + nu + 1] = off_b[1:] + self.stream_bytes
+        self.stream_bytes += int(streams_b.numel())
+        self._kind[u_old: u_old + nu] = kind_b
+        self.n_chunks, self.n_unique = n_old + n_new, u_old + nu
         self.n_done = off + n

@@ -140,6 +140,18 @@ int hmse_l3_dedup(const uint8_t* digests_all, uint64_t n_all, uint64_t* first_oc
                   uint32_t* refcount, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * L3 persistent index (README.md:1288-1292, 1542-1551: "lookup -> found: pointer, refcount++ / new: insert"; sizing
+ * README.md:1850-1894).  The table (DEVICE u32[slots], slots = hmse_l3_index_slots(capacity in chunks)) outlives the
+ * call: digests [n_old, n_old + n_new) of digests_all join a table that already holds [0, n_old) and are looked up;
+ * first_occ[n_old ..) and refcount (running counts, DEVICE u32[>= n_old + n_new]) are updated.  Earlier first
+ * occurrences never change, so a batch costs O(n_new) whatever the history.  n_old == 0 clears the table first.
+ * Returns HMSE_ENOSPC when the table would exceed load factor 0.5.
+ */
+uint64_t hmse_l3_index_slots(uint64_t capacity_chunks);
+int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, uint64_t n_new, uint64_t* first_occ,
+                         uint32_t* refcount, uint32_t* table, uint64_t slots, void* stream);
+
+/*
  * L4a — MinHash signatures.  Replaces minhash_compute(const uint8_t*, size_t,
  * uint32_t*) (README.md:2578-2598): sig[h] = min over 4-byte shingles of
  * MurmurHash3_x86_32(shingle, 4, seed_base + h).
@@ -159,6 +171,17 @@ int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* cuts,
  */
 int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* cfg, uint32_t* band_keys,
                 int64_t* base, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * L4b persistent band tables (README.md:1554-1576 "probe LSH ... none: insert signature", 1937-1945): tables DEVICE
+ * u32[bands][slots], slots = hmse_l4_lsh_slots(capacity in stored chunks), outlive the call.  Signatures
+ * [n_old, n_old + n_new) of sig_all join tables that already hold [0, n_old); band_keys[n_old ..) are written (or, with
+ * keys_given != 0, taken as loaded from a stored band table) and base[n_old ..) = earliest chunk, old or new, sharing a
+ * whole band (base may be NULL: insert only).  n_old == 0 clears the tables first.
+ */
+uint64_t hmse_l4_lsh_slots(uint64_t capacity_chunks);
+int hmse_l4_lsh_update(const uint32_t* sig_all, uint64_t n_old, uint64_t n_new, const hmse_cfg* cfg, uint32_t* band_keys,
+                       int64_t* base, uint32_t* tables, uint64_t slots, uint32_t keys_given, void* stream);
 
 /*
  * L1 — per-chunk DEFLATE (RFC 1951 raw stream) with the LSH base chunk as preset

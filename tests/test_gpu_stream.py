@@ -81,3 +81,45 @@ def test_resume_from_manifest_then_append(dev):
     for name in ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams"):
         assert torch.equal(getattr(res, name), getattr(whole, name)), name
     assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))
+
+
+def test_resume_loads_the_index_from_chunkindex_and_band_table_sidecar(dev):
+    """resume() with the band-table sidecar: digests go from the ChunkIndex records into the L3 table, band keys and
+    signatures from the sidecar into the L4 tables — nothing is re-hashed (no SHA-256 verify pass, no MinHash) — and the
+    appended batches still equal one ingest of the whole stream, bit for bit (README.md:1937-1945)."""
+    import torch
+    from hmse_amd import IngestConfig, bandtable, ingest, manifest, ops, read, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    split = 6 << 20
+    st0 = stream.StreamIngest(cfg, split, dev)
+    st0.push(torch.from_numpy(data[:split].copy()))
+    first = st0.finish()
+    blob = manifest.build_manifest(first).to_bytes()
+    side = st0.index_sidecar()
+    n_first = first.uniq_ids.numel()
+    del st0, first
+    keys, sig = bandtable.read_signatures(side)
+    assert sig.shape == (n_first, 128) and keys.shape == (n_first, 4)
+    calls = {"minhash": 0, "sha": 0}
+    real_mh, real_sha = ops.l4_minhash, ops.l3_sha256
+    def count(name, fn):
+        def w(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return w
+    ops.l4_minhash, ops.l3_sha256 = count("minhash", real_mh), count("sha", real_sha)
+    try:
+        st = stream.StreamIngest.resume(manifest.Manifest.from_bytes(blob), cfg, data.size, dev, band_tables=side, verify=False)
+        assert calls == {"minhash": 0, "sha": 0}                      # the history was loaded, not re-hashed
+    finally:
+        ops.l4_minhash, ops.l3_sha256 = real_mh, real_sha
+    st.push(torch.from_numpy(data[split:split + (2 << 20)].copy()))
+    st.push(torch.from_numpy(data[split + (2 << 20):].copy()))
+    res = st.finish()
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    for name in ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams"):
+        assert torch.equal(getattr(res, name), getattr(whole, name)), name
+    assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))
+    with pytest.raises(ValueError):
+        stream.StreamIngest.resume(manifest.Manifest.from_bytes(blob), cfg, data.size, dev, band_tables=bandtable.write_band_tables(keys[:5], 16, sig[:5]))

@@ -213,3 +213,16 @@ def test_two_shard_store_merges_and_reconstructs(orc):
     rec = p1.pointers[ptr_of_chunk[x]]
     assert np.array_equal(rec["target_lba"], store.shards[0].index["lba"][p1.chunk_map["slot"][x]]) and ((rec["flags"] >> 4) == 0).all()
     assert manifest.reconstruct(store) == data.tobytes()
+
+
+def test_band_table_sidecar_carries_keys_and_signatures():
+    from hmse_amd import bandtable
+    rng = np.random.default_rng(4)
+    keys = rng.integers(0, 2**32, (1000, 4), dtype=np.uint32)
+    sig = rng.integers(0, 2**32, (1000, 128), dtype=np.uint32)
+    buf = bandtable.write_band_tables(keys, 16, signatures=sig)
+    k2, s2 = bandtable.read_signatures(buf)
+    assert np.array_equal(k2, keys) and np.array_equal(s2, sig)
+    bits, tables = bandtable.read_band_tables(buf)                 # the reference-layout part is unchanged by the trailing section
+    assert bits == 16 and sum(int(c.sum()) for _, _, c, _ in tables) == 4000
+    assert bandtable.read_signatures(bandtable.write_band_tables(keys, 16)) == (None, None)

@@ -23,9 +23,15 @@ iters = 2 if tot <= (16 << 30) else 1
 for it in range(iters):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = stream.StreamIngest(cfg, tot, dev)
+    per_batch = []
     for a in range(0, tot, bat):
+        tb = time.perf_counter()
         st.push(host[a: a + bat])
+        if os.environ.get("STREAM_BATCH_TIMES") == "1":   # serialises copy and compute: per-batch cost vs history
+            torch.cuda.synchronize(); per_batch.append(round((time.perf_counter() - tb) * 1e3))
     res = st.finish()
+    if per_batch:
+        print("  ms per push (batch k's copy + batch k-1's kernels, synchronised):", per_batch, flush=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = res.stats
     print(f"stream iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
