@@ -457,7 +457,6 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     }
     if (t < 64) W[T + t] = 0;
     for (uint32_t i = t; i < NBK / 2; i += NT) cur[i] = 0;
-    for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;
     for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
     if (t < 32) sm.df[t] = 0;
     if (t < 20) sm.cf[t] = 0;
@@ -518,6 +517,64 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       __syncthreads();  // cursor h now = end of bucket h
     }
     STAMP(2);
+    // ---- phase 4b (dictionary jobs): diagonal anchors ------------------------------------------------
+    // A chunk with an LSH base is a near-duplicate of it: most positions have a 258-byte match in the dictionary on the
+    // same diagonal as their neighbours, and comparing those bytes again at every position is most of a dictionary job's
+    // matcher time.  So one position in 64 (an ANCHOR) looks for a long dictionary match cooperatively — the wavefront's
+    // lanes take the bucket's nearest dictionary members, then compare 512 bytes along the best one's diagonal at once —
+    // and records (distance d, run length).  That is a true statement about the window, "W[x] == W[x - d] for x in
+    // [anchor, anchor + run), and not at anchor + run", from which the matcher below knows the exact common prefix of any
+    // position p in that run with its candidate p - d WITHOUT reading a byte.  The match results stay those of the
+    // definition (the oracle's serial walk): a hint only replaces one candidate's byte compare by its known outcome.
+    uint32_t* const anch = mark;   // u32[ceil(L / 64)]: d | run << 16, 0 = none (DICT only)
+    if constexpr (DICT) {
+      const uint32_t n_anch = (L + 63u) >> 6;
+      for (uint32_t a0 = wave; a0 < n_anch; a0 += NT / 64) {
+        const uint32_t pa = Dl + (a0 << 6);
+        uint32_t word = 0;
+        if (pa + 4 <= T) {
+          const uint32_t h = hash4(ld32a(W, pa));
+          const uint32_t lo = h ? cur_get(cur, h - 1) : 0u, hi = cur_get(cur, h);
+          uint32_t l = lo, r = hi;   // bucket members ascend: dictionary positions first; [lo, l) after the search
+          while (l < r) { const uint32_t m = (l + r) >> 1; if ((uint32_t)S[m] < Dl) l = m + 1; else r = m; }
+          const uint32_t first = l > lo + 64u ? l - 64u : lo;   // the (up to) 64 nearest dictionary members
+          const uint32_t idx = first + lane;
+          uint32_t ml = 0, q = 0;
+          if (idx < l) {
+            q = S[idx];
+            if (TCAP <= (int)WMAX || pa - q <= WMAX) {
+              uint64_t qa[4], pb[4];
+              ldNa<4>(W, q, qa); ldNa<4>(W, pa, pb);
+              ml = 32;
+#pragma unroll
+              for (int u = 3; u >= 0; u--) { const uint64_t x = qa[u] ^ pb[u]; if (x) ml = 8u * u + ((uint32_t)__builtin_ctzll(x) >> 3); }
+            }
+          }
+          uint32_t key = (ml << 8) | lane;   // longest, then nearest (highest lane)
+#pragma unroll
+          for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)key, sft, 64); key = key > o ? key : o; }
+          if ((key >> 8) >= 32u) {
+            const uint32_t d = pa - (uint32_t)__shfl((int)q, (int)(key & 63u), 64);
+            // 512 bytes along the diagonal, 8 per lane
+            const uint32_t off = 8u * lane;
+            uint32_t n = 8;
+            if (pa + off < T) {
+              uint64_t xa[1], xb[1];
+              ldNa<1>(W, pa + off - d, xa); ldNa<1>(W, pa + off, xb);
+              const uint64_t x = xa[0] ^ xb[0];
+              if (x) n = (uint32_t)__builtin_ctzll(x) >> 3;
+            } else n = 0;
+            const uint64_t mm = __ballot(n < 8u);
+            uint32_t run = 512;
+            if (mm) { const uint32_t fl = (uint32_t)__builtin_ctzll(mm); run = 8u * fl + (uint32_t)__shfl((int)n, (int)fl, 64); }
+            if (run > T - pa) run = T - pa;
+            word = d | (run << 16);
+          }
+        }
+        anch[a0] = word;   // every lane, same value
+      }
+      __syncthreads();
+    }
     // ---- phase 5: longest match for every chunk position ----------------------------------------
     // Bucket sizes and match lengths are heavily skewed (a few hot 4-grams hold most candidates), so a
     // lane does NOT own a fixed set of positions: every lane is a small state machine that pulls the
@@ -530,6 +587,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
+      uint32_t ph = 0;   // dictionary jobs: diagonal hint of the current position, q' | known length << 16 (0 = none)
       for (;;) {
 #ifdef HMSE_DFL_STAMPS
         if (t == 0) stamp_acc[13]++;  // trips of wavefront 0 through the state machine
@@ -556,6 +614,31 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
                 kmax = i - lo;
                 if (kmax > a.depth) kmax = a.depth;
                 best = MINM - 1; bd = 0; probe = pw0; kk = 1;
+                if constexpr (DICT) {
+                  // diagonal hint: a dictionary candidate q' = p - d of this position whose common prefix with p is known
+                  // exactly from an anchor's run (this block's anchor or the previous one's), usable iff q' is one of the
+                  // candidates the walk will reach
+                  ph = 0;
+                  if (kmax != 0) {
+                    const uint32_t a0 = (p - Dl) >> 6;
+                    uint32_t bm = 0, bq = 0;
+#pragma unroll
+                    for (uint32_t back = 0; back < 2; back++) {
+                      if (a0 < back) continue;
+                      const uint32_t w = anch[a0 - back];
+                      const uint32_t d = w & 0xFFFFu, run = w >> 16, pa = Dl + ((a0 - back) << 6);
+                      if (w == 0 || p < pa || d > p || p - d >= Dl) continue;      // (p < pa: this block's anchor IS p's block start)
+                      uint32_t m = 0;
+                      if (run >= 512u) m = maxlen;                                   // no mismatch within 512 bytes: >= 385 from here
+                      else if (pa + run > p) m = (pa + run - p) < maxlen ? (pa + run - p) : maxlen;
+                      if (m > bm) { bm = m; bq = p - d; }
+                    }
+                    if (bm >= 16u && (uint32_t)S[i - kmax] <= bq) ph = bq | (bm << 16);
+#ifdef HMSE_DFL_STAMPS
+                    if (t == 0) { stamp_acc[6]++; if (bm >= 16u) stamp_acc[7]++; if (ph) stamp_acc[8]++; }  // lane 0's positions: fetched / hinted / usable
+#endif
+                  }
+                }
                 if (kmax != 0) st = PROBE;  // first of its bucket: no match, pull again
               }
             }
@@ -571,6 +654,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (variant && q < Dl && !(bd >> 31)) {
             if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
             bd |= 0x80000000u;
+            // with a hint, candidate q' (farther on in this walk) is known to reach ph >> 16 bytes: a nearer dictionary candidate
+            // only matters if it reaches as many (it then wins the tie), so the filters may already work with that length
+            if (DICT && ph && (ph >> 16) - 1u > best) { best = (ph >> 16) - 1u; probe = ld32a(W, p + best - 3); }
           }
           // a candidate the byte-4 filter rejects (37 % of them on text) is consumed on the spot and the next one takes
           // its place in this trip: the filter needs nothing but the two prefetched values
@@ -582,10 +668,12 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             if (variant && q < Dl && !(bd >> 31)) {
               if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
               bd |= 0x80000000u;
+              if (DICT && ph && (ph >> 16) - 1u > best) { best = (ph >> 16) - 1u; probe = ld32a(W, p + best - 3); }
             }
           }
           fin = true; ml = 0;
-          if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
+          if (DICT && ph && q == (ph & 0xFFFFu)) ml = ph >> 16;        // the hinted candidate: its length is known, no byte is read
+          else if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;        // farther ones are farther still
           else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
           else {
             // random-address window reads only for candidates that can still win
@@ -643,6 +731,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       }
     }
     __syncthreads();
+    for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;   // (held the diagonal anchors of a dictionary job until here)
     STAMP(3);
     // pass 0: this job's own record (DELTA for a dictionary job); pass 1 (dictionary jobs only): the FULL record
     for (uint32_t pass = 0; pass < (variant ? 2u : 1u); pass++) {

@@ -43,7 +43,11 @@ print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base
 for c, cn in enumerate(["class S (T <= 9216)", "classes S2, SG (T <= 16000)", "classes SG2, SG3, B (dictionary jobs and big chunks)"]):
     row = buf[c * 16:(c + 1) * 16].astype(np.float64)
     trips, positions, jobs = row[13], row[14], row[15]
+    fetched, hinted, usable = row[6], row[7], row[8]
+    row[6:9] = 0
     row[13:] = 0
+    if fetched:
+        print(cn, "dictionary-job positions of lane 0: %d with candidates, %.1f %% have a diagonal hint, %.1f %% a usable one" % (fetched, 100 * hinted / fetched, 100 * usable / fetched))
     tot = row.sum()
     if tot == 0:
         continue
