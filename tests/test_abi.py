@@ -120,3 +120,18 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".c", ".cpp")):
                 src = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, fn
+
+
+def test_torch_ops_are_registered_and_have_no_cpu_path():
+    """the stage operators are reachable as torch.ops.hmse.* (tensors in, tensors out); like ops.py they
+    refuse host tensors — there is no CPU implementation behind the registration."""
+    import torch
+    from hmse_amd import ops, torch_ops  # noqa: F401  (importing registers the library)
+    for name in ("l2_cdc", "l3_sha256", "l3_dedup", "l4_minhash", "l4_lsh", "l1_deflate", "l1_inflate"):
+        assert hasattr(torch.ops.hmse, name), name
+    assert "min_size" in str(torch.ops.hmse.l2_cdc.default._schema)
+    x = torch.zeros(5000, dtype=torch.uint8)
+    with pytest.raises(ops.HmseError):
+        torch.ops.hmse.l2_cdc(x)
+    with pytest.raises(ops.HmseError):
+        torch.ops.hmse.l3_sha256(x, torch.tensor([0, 5000]))

@@ -253,3 +253,26 @@ def test_l1_deflate_selection(orc, dev, corpus_small):
     assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
     assert np.array_equal(out.cpu().numpy(), want_out)
     assert np.array_equal(kind.cpu().numpy(), want_kind)
+
+
+def test_torch_ops_hmse_equal_the_operator_functions(dev, corpus_small):
+    """torch.ops.hmse.*  run the same C-ABI calls as hmse_amd.ops."""
+    import torch
+    from hmse_amd import IngestConfig, ops, torch_ops  # noqa: F401
+    cfg = IngestConfig()
+    d = to_dev(corpus_small[: 2 << 20], dev)
+    cuts = torch.ops.hmse.l2_cdc(d)
+    assert torch.equal(cuts, ops.l2_cdc(d, cfg))
+    dg = torch.ops.hmse.l3_sha256(d, cuts)
+    assert torch.equal(dg, ops.l3_sha256(d, cuts))
+    fo, rc = torch.ops.hmse.l3_dedup(dg)
+    uniq = (fo == torch.arange(fo.numel(), device=dev)).nonzero().flatten()
+    sig = torch.ops.hmse.l4_minhash(d, cuts, uniq)
+    assert torch.equal(sig, ops.l4_minhash(d, cuts, cfg, uniq))
+    keys, base = torch.ops.hmse.l4_lsh(sig)
+    out, off, kind = torch.ops.hmse.l1_deflate(d, cuts, uniq, base)
+    o2, f2, k2 = ops.l1_deflate(d, cuts, cfg, uniq, base)
+    assert torch.equal(out, o2) and torch.equal(off, f2) and torch.equal(kind, k2)
+    lens = (cuts[1:] - cuts[:-1])[uniq]
+    raw, raw_off, ok = torch.ops.hmse.l1_inflate(out, off, kind, base, lens)
+    assert bool(ok.all()) and raw.numel() == int(lens.sum())
