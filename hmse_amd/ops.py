@@ -192,11 +192,13 @@ def record_bytes(lens: torch.Tensor) -> torch.Tensor:
 
 
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
-               base: torch.Tensor | None = None, base_is_chunk_id: bool = False):
+               base: torch.Tensor | None = None, base_is_chunk_id: bool = False, ws: torch.Tensor | None = None):
     """Per-chunk raw DEFLATE with the base chunk as dictionary (`base`: index into the selection, or — with
     base_is_chunk_id — a chunk index into `cuts`, e.g. a chunk stored by an earlier batch of a stream).
 
     Returns (out uint8[total], out_off int64[n_sel+1], kind uint8[n_sel]). README.md:2374-2378, 2182-2189."""
+    if ws is not None:
+        _require_gpu(ws, "ws")
     _require_gpu(data, "data")
     _require_gpu(cuts, "cuts")
     dev = data.device
@@ -216,7 +218,8 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     c = cfg.to_c()
     nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
-    ws = _ws(nb + need + 4096, dev)
+    if ws is None or ws.numel() < nb + need + 4096:   # (`ws`: a caller-held workspace, e.g. the streaming front end's, reused when big enough)
+        ws = _ws(nb + need + 4096, dev)
     rc = _lib.hip_lib().hmse_l1_deflate_ex(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
                                            1 if base_is_chunk_id else 0, _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status),
                                            ws.data_ptr(), ws.numel(), _stream())

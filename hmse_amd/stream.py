@@ -54,6 +54,7 @@ class StreamIngest:
         self.n_unique = 0
         self.stream_bytes = 0
         self.stream_parts: list[torch.Tensor] = []
+        self._ws = None             # DEFLATE workspace, kept across batches
 
     # views of the filled part of the index
     cuts = property(lambda self: self._cuts[: self.n_chunks + 1])
@@ -190,7 +191,13 @@ class StreamIngest:
         base_new = self._base[u_old: u_old + nu]
         # L1: the dictionary may be a chunk of an earlier batch -> bases as chunk indices
         base_chunk = torch.where(base_new >= 0, self._uniq[base_new.clamp(min=0)], base_new)
-        streams_b, off_b, kind_b = ops.l1_deflate(all_data, cuts_all, cfg, uniq_new, base_chunk, base_is_chunk_id=True)
+        # one workspace for every batch, sized for the worst case of this batch (every chunk stored, every one with a dictionary):
+        # a fresh multi-GB allocation per batch synchronises the device and stalls the copy/compute overlap
+        worst = 2 * (5 * n + 1600 * n_new) + ops.workspace_bytes(ops.STAGE_DEFLATE, n_new, cfg) + (1 << 20)
+        if self._ws is None or self._ws.numel() < worst:
+            self._ws = None
+            self._ws = torch.empty(worst, dtype=torch.uint8, device=dev)
+        streams_b, off_b, kind_b = ops.l1_deflate(all_data, cuts_all, cfg, uniq_new, base_chunk, base_is_chunk_id=True, ws=self._ws)
         self.stream_parts.append(streams_b)
         self._stream_off[u_old + 1: u_old + nu + 1] = off_b[1:] + self.stream_bytes
         self.stream_bytes += int(streams_b.numel())
