@@ -88,3 +88,32 @@ void hmse_prof_end(int stage, hipStream_t s);
 int hmse_cfg_validate_impl(const hmse_cfg* cfg);
 void hmse_cdc_masks_hi(const hmse_cfg* cfg, uint32_t* ms_hi, uint32_t* ml_hi);
 uint32_t hmse_deflate_depth(const hmse_cfg* cfg);
+
+// ---- device-side state of the captured per-batch chain (hmse_stream_batch, stream_batch.hip) ---------------------
+// u64 words in HBM, read by every stage instead of host-side counts, so that the whole chain of one batch can be
+// enqueued (and captured into a hipGraph) without a single host read.
+enum {
+  SB_OFF = 0,        // byte offset of this batch in the resident corpus (= bytes ingested before it)
+  SB_N_OLD = 1,      // chunks before this batch
+  SB_N_NEW = 2,      // chunks of this batch            (written by the chain)
+  SB_U_OLD = 3,      // stored chunks before this batch
+  SB_U_NEW = 4,      // stored chunks of this batch     (written by the chain)
+  SB_S_OLD = 5,      // stream bytes before this batch
+  SB_S_NEW = 6,      // stream bytes of this batch      (written by the chain)
+  SB_STATUS = 7,     // sticky error bits
+  SB_WORDS = 16
+};
+int hmse_l2_cdc_impl(const uint8_t* data, const uint64_t* data_off_dev, uint64_t n, const uint64_t* seg_off, uint32_t n_seg,
+                     const hmse_cfg* cfg, uint64_t* cuts, uint64_t cuts_cap, uint64_t* n_cuts, uint32_t* status, void* ws,
+                     size_t ws_bytes, hipStream_t stream);
+int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, const uint64_t* st,
+                       uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream);
+int hmse_l3_index_update_dyn(const uint8_t* digests_all, uint64_t* first_occ, uint32_t* refcount, uint32_t* table, uint64_t slots,
+                             const uint64_t* st, uint64_t cap_chunks, hipStream_t stream);
+int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
+                        const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream);
+int hmse_l4_lsh_update_dyn(const uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* tables, uint64_t slots,
+                           const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream);
+int hmse_l1_deflate_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* sel_ids, const int64_t* sel_base,
+                        const uint64_t* n_sel_dev, uint64_t cap_sel, const uint64_t* out_base_dev, const hmse_cfg* cfg, uint8_t* out,
+                        uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, hipStream_t stream);

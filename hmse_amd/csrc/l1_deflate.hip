@@ -1167,7 +1167,9 @@ static_assert(2 * Layout<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>::TOTA
 // job = (k << 1) | variant, appended to its size class's list
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel, uint32_t base_is_chunk,
-                                                        uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts) {
+                                                        uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts,
+                                                        const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n_sel = *n_dev;   // captured chain: the count lives in HBM, the grid is sized for the worst case
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // wave-aggregated append (one atomic per class per wavefront instead of one per job)
   auto append = [&](bool on, uint32_t cl, uint32_t job) {
@@ -1208,7 +1210,8 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
 // record sizes: FULL (+ DELTA when a base exists)
 __global__ __launch_bounds__(256) void rec_size_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel,
-                                                        uint64_t* __restrict__ sizes) {
+                                                        uint64_t* __restrict__ sizes, const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n_sel = *n_dev;
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_sel) return;
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
@@ -1222,7 +1225,8 @@ __global__ __launch_bounds__(256) void decide_kernel(const uint64_t* __restrict_
                                                       const int64_t* __restrict__ base, uint64_t n_sel,
                                                       const uint32_t* __restrict__ len_full, const uint32_t* __restrict__ len_delta,
                                                       uint32_t pct, uint64_t* __restrict__ final_len, uint8_t* __restrict__ kind,
-                                                      uint32_t* status) {
+                                                      uint32_t* status, const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n_sel = *n_dev;
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_sel) return;
   const uint32_t n1 = len_full[k];
@@ -1244,17 +1248,20 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint64_t* __restrict_
                                                       uint64_t n_sel, const uint64_t* __restrict__ rec_off,
                                                       const uint8_t* __restrict__ recs, const uint8_t* __restrict__ kind,
                                                       const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out,
-                                                      uint64_t out_cap, uint32_t* status) {
+                                                      uint64_t out_cap, uint32_t* status, const uint64_t* __restrict__ n_dev,
+                                                      const uint64_t* __restrict__ out_base_dev) {
+  if (n_dev) n_sel = *n_dev;
   const uint64_t k = blockIdx.x;
   if (k >= n_sel) return;
+  const uint64_t obase = out_base_dev ? *out_base_dev : 0ull;   // captured chain: streams are appended behind the earlier batches'
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
   const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
   if (len > 32768u) return;
   const uint8_t* src = recs + rec_off[k] + ((kind && kind[k] == HMSE_KIND_DELTA) ? rec_size(len) : 0u) + rec_slot_off(len);
   const uint64_t o0 = out_off[k], o1 = out_off[k + 1];
-  if (o1 > out_cap) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
+  if (obase + o1 > out_cap) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
   const uint32_t nb = (uint32_t)(o1 - o0);
-  uint8_t* dst = out + o0;
+  uint8_t* dst = out + obase + o0;
   for (uint32_t i = threadIdx.x * 16; i < nb; i += blockDim.x * 16) {
     if (i + 16 <= nb) { const uint4 v = *(const uint4*)(src + i); __builtin_memcpy(dst + i, &v, 16); }
     else for (uint32_t b = i; b < nb; b++) dst[b] = src[b];
@@ -1263,7 +1270,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint64_t* __restrict_
 
 // ---- u64 exclusive scan (three small kernels) ---------------------------------------------------------------
 constexpr int SC_NT = 1024;
-__global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ bsum) {
+__global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ bsum,
+                                                            const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n = *n_dev;
   __shared__ unsigned long long s[SC_NT / 64];
   const uint64_t i = (uint64_t)blockIdx.x * SC_NT + threadIdx.x;
   unsigned long long v = i < n ? in[i] : 0ull;
@@ -1272,7 +1281,8 @@ __global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(const uint64_t* __re
   __syncthreads();
   if (threadIdx.x == 0) { unsigned long long tt = 0; for (int w = 0; w < SC_NT / 64; w++) tt += s[w]; bsum[blockIdx.x] = tt; }
 }
-__global__ __launch_bounds__(SC_NT) void scan_blocks_kernel(uint64_t* bsum, uint64_t nb, uint64_t* total_out) {
+__global__ __launch_bounds__(SC_NT) void scan_blocks_kernel(uint64_t* bsum, uint64_t nb, uint64_t* total_out, const uint64_t* __restrict__ n_dev) {
+  if (n_dev) nb = (*n_dev + SC_NT - 1) / SC_NT;
   __shared__ unsigned long long s[SC_NT / 64 + 1];
   __shared__ unsigned long long run;
   if (threadIdx.x == 0) run = 0;
@@ -1295,7 +1305,8 @@ __global__ __launch_bounds__(SC_NT) void scan_blocks_kernel(uint64_t* bsum, uint
   if (threadIdx.x == 0 && total_out) *total_out = run;
 }
 __global__ __launch_bounds__(SC_NT) void scan_apply_kernel(const uint64_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ bsum,
-                                                            uint64_t* __restrict__ out) {
+                                                            uint64_t* __restrict__ out, const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n = *n_dev;
   __shared__ unsigned long long s[SC_NT / 64];
   const uint64_t i = (uint64_t)blockIdx.x * SC_NT + threadIdx.x;
   const unsigned long long v = i < n ? in[i] : 0ull;
@@ -1306,14 +1317,18 @@ __global__ __launch_bounds__(SC_NT) void scan_apply_kernel(const uint64_t* __res
   unsigned long long wb = 0;
   for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wb += s[w];
   if (i < n) out[i] = bsum[blockIdx.x] + wb + inc - v;
+  if (i + 1 == n) out[n] = bsum[blockIdx.x] + wb + inc;   // the total also behind the last element (out has n + 1 entries): with a
+                                                           // device-side n the caller's `total` pointer sits at the worst-case index
 }
 
 // out[0..n) = exclusive scan of in; *total (device) = sum. in and out may alias.
-static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* bsum, uint64_t* total, hipStream_t stream) {
+// (n_dev != nullptr: the element count is read on the device, `n` is the worst case the grids are sized for)
+static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uint64_t* bsum, uint64_t* total, hipStream_t stream,
+                              const uint64_t* n_dev = nullptr) {
   const uint64_t nb = (n + SC_NT - 1) / SC_NT;
-  scan_reduce_kernel<<<dim3((uint32_t)nb), dim3(SC_NT), 0, stream>>>(in, n, bsum);
-  scan_blocks_kernel<<<dim3(1), dim3(SC_NT), 0, stream>>>(bsum, nb, total);
-  scan_apply_kernel<<<dim3((uint32_t)nb), dim3(SC_NT), 0, stream>>>(in, n, bsum, out);
+  scan_reduce_kernel<<<dim3((uint32_t)nb), dim3(SC_NT), 0, stream>>>(in, n, bsum, n_dev);
+  scan_blocks_kernel<<<dim3(1), dim3(SC_NT), 0, stream>>>(bsum, nb, total, n_dev);
+  scan_apply_kernel<<<dim3((uint32_t)nb), dim3(SC_NT), 0, stream>>>(in, n, bsum, out, n_dev);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
 
@@ -1372,10 +1387,34 @@ extern "C" uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len) { return ch
 // fixed part only; the caller adds the slot area: sum over chunks of align16(len+5) * (1 + has_base)
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_sel, const hmse_cfg*) { return dfl::carve(nullptr, n_sel).fixed_bytes; }
 
+static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
+                        const int64_t* base, uint64_t n_sel, const uint64_t* n_dev, const uint64_t* out_base_dev, const hmse_cfg* cfg, uint32_t flags,
+                        uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes,
+                        void* stream_);
+
 extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
                                   const int64_t* base, uint64_t n_sel, const hmse_cfg* cfg, uint32_t flags, uint8_t* out,
                                   uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes,
                                   void* stream_) {
+  return deflate_impl(data, n, cuts, chunk_ids, base, n_sel, nullptr, nullptr, cfg, flags, out, out_cap, out_off, kind, status, ws, ws_bytes, stream_);
+}
+
+// captured chain: the selection's size is *n_sel_dev (<= cap_sel, which sizes grids and workspace); bases are chunk ids; the total
+// stream size lands in out_off[cap_sel]
+int hmse_l1_deflate_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* sel_ids, const int64_t* sel_base,
+                        const uint64_t* n_sel_dev, uint64_t cap_sel, const uint64_t* out_base_dev, const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap,
+                        uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!n_sel_dev || cap_sel == 0) return HMSE_EINVAL;
+  return deflate_impl(data, n_cap, cuts_all, sel_ids, sel_base, cap_sel, n_sel_dev, out_base_dev, cfg, HMSE_DEFLATE_BASE_IS_CHUNK_ID, out, out_cap, out_off,
+                      kind, status, ws, ws_bytes, (void*)stream);
+}
+
+// n_dev == nullptr: n_sel is the selection's size.  n_dev != nullptr: n_sel is the worst case (grids, workspace carve), the real
+// size is read on the device by every kernel that needs it.
+static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
+                        const int64_t* base, uint64_t n_sel, const uint64_t* n_dev, const uint64_t* out_base_dev, const hmse_cfg* cfg, uint32_t flags,
+                        uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes,
+                        void* stream_) {
   using namespace dfl;
   if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
   if (flags & ~(uint32_t)HMSE_DEFLATE_BASE_IS_CHUNK_ID) return HMSE_EINVAL;
@@ -1396,10 +1435,10 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
   HMSE_HIP(hipMemsetAsync(w.len_full, 0, n_sel * sizeof(uint32_t), stream));
   HMSE_HIP(hipMemsetAsync(w.len_delta, 0, n_sel * sizeof(uint32_t), stream));
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
-  rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off);
+  rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off, n_dev);
   HMSE_LAUNCH_CHECK();
-  if (exclusive_scan_u64(w.rec_off, n_sel, w.rec_off, w.bsum, w.rec_total, stream) != HMSE_OK) return HMSE_EHIP;
-  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, a_base_is_chunk, w.lists, w.list_stride, w.counters);
+  if (exclusive_scan_u64(w.rec_off, n_sel, w.rec_off, w.bsum, w.rec_total, stream, n_dev) != HMSE_OK) return HMSE_EHIP;
+  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, a_base_is_chunk, w.lists, w.list_stride, w.counters, n_dev);
   HMSE_LAUNCH_CHECK();
   Args a;
   a.data = data; a.n = n; a.cuts = cuts; a.chunk_ids = chunk_ids; a.base = base; a.n_sel = n_sel;
@@ -1451,11 +1490,11 @@ extern "C" int hmse_l1_deflate_ex(const uint8_t* data, uint64_t n, const uint64_
     HMSE_LAUNCH_CHECK();
   }
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
-                                                        cfg->delta_max_ratio_pct, w.final_len, kind, status);
+                                                        cfg->delta_max_ratio_pct, w.final_len, kind, status, n_dev);
   HMSE_LAUNCH_CHECK();
-  if (exclusive_scan_u64(w.final_len, n_sel, out_off, w.bsum, out_off + n_sel, stream) != HMSE_OK) return HMSE_EHIP;
+  if (exclusive_scan_u64(w.final_len, n_sel, out_off, w.bsum, out_off + n_sel, stream, n_dev) != HMSE_OK) return HMSE_EHIP;
   gather_kernel<<<dim3((uint32_t)n_sel), dim3(256), 0, stream>>>(cuts, chunk_ids, n_sel, w.rec_off, w.recs, kind, out_off, out,
-                                                                out_cap, status);
+                                                                out_cap, status, n_dev, out_base_dev);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

@@ -62,10 +62,11 @@ __device__ __forceinline__ uint64_t gear_lookup(const uint64_t* lg, uint32_t byt
   return lg[byte * COPIES + copy];
 }
 
-__global__ __launch_bounds__(L2_NT) void l2_hash_kernel(const uint8_t* __restrict__ data, uint64_t n,
+__global__ __launch_bounds__(L2_NT) void l2_hash_kernel(const uint8_t* __restrict__ data0, const uint64_t* __restrict__ data_off, uint64_t n,
                                                           uint32_t thr_l, uint32_t thr_s,
                                                           uint32_t* __restrict__ cand, uint64_t cand_cap,
                                                           TileInfo* __restrict__ tinfo, L2Header* hdr) {
+  const uint8_t* __restrict__ data = data0 + (data_off ? *data_off : 0ull);   // (captured chain: the batch's offset lives in HBM)
 #ifndef HMSE_L2_DIRECT
   __shared__ __attribute__((aligned(16))) uint8_t s_data[(L2_NT + 1) * L2_PSTRIDE];
 #endif
@@ -439,6 +440,12 @@ size_t hmse_l2_workspace_bytes_impl(uint64_t n, uint32_t n_seg, const hmse_cfg* 
 extern "C" int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_off, uint32_t n_seg,
                            const hmse_cfg* cfg, uint64_t* cuts, uint64_t cuts_cap, uint64_t* n_cuts,
                            uint32_t* status, void* ws, size_t ws_bytes, void* stream_) {
+  return hmse_l2_cdc_impl(data, nullptr, n, seg_off, n_seg, cfg, cuts, cuts_cap, n_cuts, status, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+int hmse_l2_cdc_impl(const uint8_t* data, const uint64_t* data_off_dev, uint64_t n, const uint64_t* seg_off, uint32_t n_seg,
+                     const hmse_cfg* cfg, uint64_t* cuts, uint64_t cuts_cap, uint64_t* n_cuts, uint32_t* status, void* ws,
+                     size_t ws_bytes, hipStream_t stream_) {
   if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
   if (!cuts || !n_cuts || !status || !seg_off || cuts_cap < 1) return HMSE_EINVAL;
   if (n > 0 && !data) return HMSE_EINVAL;
@@ -454,7 +461,7 @@ extern "C" int hmse_l2_cdc(const uint8_t* data, uint64_t n, const uint64_t* seg_
   if (n_tiles > 0x7FFFFFFFull) return HMSE_EINVAL;
   if (n_tiles) {
     PROF_BEGIN(HMSE_STAGE_L2_CDC, stream);
-  l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, n, ~ml_hi + 1u, ms_hi == 0xFFFFFFFFu ? 1u : ~ms_hi + 1u, w.cand, w.cand_cap, w.tinfo, w.hdr);
+  l2_hash_kernel<<<dim3((uint32_t)n_tiles), dim3(L2_NT), 0, stream>>>(data, data_off_dev, n, ~ml_hi + 1u, ms_hi == 0xFFFFFFFFu ? 1u : ~ms_hi + 1u, w.cand, w.cand_cap, w.tinfo, w.hdr);
   PROF_END(HMSE_STAGE_L2_CDC, stream);
     HMSE_LAUNCH_CHECK();
   }

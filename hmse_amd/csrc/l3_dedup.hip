@@ -28,7 +28,8 @@ __device__ __forceinline__ bool key_equal(const uint8_t* keys, size_t stride, ui
 template <int KEY_U4>
 __global__ __launch_bounds__(256) void fo_insert_kernel(const uint8_t* __restrict__ keys, size_t stride,
                                                          const uint32_t* __restrict__ hashes, uint64_t i0, uint64_t n, uint32_t* table,
-                                                         uint32_t mask) {
+                                                         uint32_t mask, const uint64_t* __restrict__ st = nullptr) {
+  if (st) { i0 = st[SB_N_OLD]; n = st[SB_N_NEW]; }
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
   const uint32_t i = (uint32_t)(i0 + i64);   // entries [i0, i0 + n) join a table that may already hold [0, i0)
@@ -65,7 +66,9 @@ __device__ __forceinline__ uint32_t fo_lookup(const uint8_t* keys, size_t stride
 
 __global__ __launch_bounds__(256) void dedup_lookup_kernel(const uint8_t* __restrict__ digests, uint64_t i0, uint64_t n,
                                                             const uint32_t* __restrict__ table, uint32_t mask,
-                                                            uint64_t* __restrict__ first_occ, uint32_t* __restrict__ refcount) {
+                                                            uint64_t* __restrict__ first_occ, uint32_t* __restrict__ refcount,
+                                                            const uint64_t* __restrict__ st = nullptr) {
+  if (st) { i0 = st[SB_N_OLD]; n = st[SB_N_NEW]; }
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
   const uint32_t i = (uint32_t)(i0 + i64);
@@ -123,6 +126,23 @@ extern "C" int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, 
   fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, n_old, n_new, table, (uint32_t)(slots - 1));
   HMSE_LAUNCH_CHECK();
   dedup_lookup_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, n_old, n_new, table, (uint32_t)(slots - 1), first_occ, refcount);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+__global__ __launch_bounds__(256) void zero_refcount_kernel(uint32_t* __restrict__ refcount, const uint64_t* __restrict__ st) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < st[SB_N_NEW]) refcount[st[SB_N_OLD] + i] = 0;
+}
+// captured chain: range from the device state, grids sized for cap_chunks (the table is never cleared here: the caller's
+// first hmse_l3_index_update / a memset did that)
+int hmse_l3_index_update_dyn(const uint8_t* digests_all, uint64_t* first_occ, uint32_t* refcount, uint32_t* table, uint64_t slots,
+                             const uint64_t* st, uint64_t cap_chunks, hipStream_t stream) {
+  if (!digests_all || !first_occ || !refcount || !table || !st || slots < 1024 || (slots & (slots - 1)) || slots > (1ull << 31)) return HMSE_EINVAL;
+  const uint32_t blocks = (uint32_t)((cap_chunks + 255) / 256);
+  zero_refcount_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(refcount, st);
+  fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, 0, 0, table, (uint32_t)(slots - 1), st);
+  dedup_lookup_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 0, 0, table, (uint32_t)(slots - 1), first_occ, refcount, st);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

@@ -49,7 +49,8 @@ __device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) 
 __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                          const uint64_t* __restrict__ cuts, uint64_t n_chunks,
                                                          uint8_t* __restrict__ digests, unsigned long long* counter,
-                                                         const uint32_t* __restrict__ order) {
+                                                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ sbst) {
+  if (sbst) { cuts += sbst[SB_N_OLD]; digests += 32 * sbst[SB_N_OLD]; n_chunks = sbst[SB_N_NEW]; }   // captured chain: this batch's chunks
   const uint32_t lane = lane_id();
   // per-lane chunk state
   uint64_t idx = 0, cur = 0, len = 0;
@@ -163,7 +164,9 @@ __device__ __forceinline__ uint32_t ord_key(uint64_t len) {
   const uint64_t nb = (len + 9 + 63) / 64;
   return ORD_BINS - 1 - (uint32_t)(nb < ORD_BINS - 1 ? nb : ORD_BINS - 1);  // descending length
 }
-__global__ __launch_bounds__(256) void ord_hist_kernel(const uint64_t* __restrict__ cuts, uint64_t n, uint32_t* __restrict__ bins) {
+__global__ __launch_bounds__(256) void ord_hist_kernel(const uint64_t* __restrict__ cuts, uint64_t n, uint32_t* __restrict__ bins,
+                                                        const uint64_t* __restrict__ st) {
+  if (st) { cuts += st[SB_N_OLD]; n = st[SB_N_NEW]; }
   __shared__ uint32_t s_bins[ORD_BINS];
   for (uint32_t i = threadIdx.x; i < ORD_BINS; i += 256) s_bins[i] = 0;
   __syncthreads();
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(ORD_BINS) void ord_scan_kernel(uint32_t* __restrict
   bins[threadIdx.x] = block_exclusive_scan<ORD_BINS>(v, s_red, &total);
 }
 __global__ __launch_bounds__(256) void ord_scatter_kernel(const uint64_t* __restrict__ cuts, uint64_t n, uint32_t* __restrict__ bins,
-                                                           uint32_t* __restrict__ order) {
+                                                           uint32_t* __restrict__ order, const uint64_t* __restrict__ st) {
+  if (st) { cuts += st[SB_N_OLD]; n = st[SB_N_NEW]; }
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) order[atomicAdd(&bins[ord_key(cuts[i + 1] - cuts[i])], 1u)] = (uint32_t)i;
 }
@@ -202,9 +206,9 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
     HMSE_HIP(hipMemsetAsync(ws, 0, 256 + ORD_BINS * 4, stream));
     uint64_t hb = (n_chunks + 255) / 256;
     if (hb > 1024) hb = 1024;
-    ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts, n_chunks, bins);
+    ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts, n_chunks, bins, nullptr);
     ord_scan_kernel<<<dim3(1), dim3(ORD_BINS), 0, stream>>>(bins);
-    ord_scatter_kernel<<<dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts, n_chunks, bins, order);
+    ord_scatter_kernel<<<dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts, n_chunks, bins, order, nullptr);
     HMSE_LAUNCH_CHECK();
   } else {
     HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
@@ -215,8 +219,29 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   uint64_t blocks = (n_chunks + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   PROF_BEGIN(HMSE_STAGE_L3_SHA256, stream);
-  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws, order);
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws, order, nullptr);
   PROF_END(HMSE_STAGE_L3_SHA256, stream);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+// Captured chain: the chunks [st[SB_N_OLD], + st[SB_N_NEW]) of cuts_all, counts read on the device, grids sized for cap_chunks.
+// Always hands chunks out longest first (same digests either way: the order only schedules).
+int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, const uint64_t* st,
+                       uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!data || !cuts_all || !digests_all || !st || cap_chunks == 0 || cap_chunks >= 0xFFFFFFFFull) return HMSE_EINVAL;
+  if (!ws || ws_bytes < hmse_l3_sha256_workspace_bytes_impl(cap_chunks)) return HMSE_ENOSPC;
+  uint32_t* bins = (uint32_t*)((uint8_t*)ws + 256);
+  uint32_t* order = bins + ORD_BINS;
+  HMSE_HIP(hipMemsetAsync(ws, 0, 256 + ORD_BINS * 4, stream));
+  uint64_t hb = (cap_chunks + 255) / 256;
+  if (hb > 1024) hb = 1024;
+  ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts_all, 0, bins, st);
+  ord_scan_kernel<<<dim3(1), dim3(ORD_BINS), 0, stream>>>(bins);
+  ord_scatter_kernel<<<dim3((uint32_t)((cap_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts_all, 0, bins, order, st);
+  uint64_t blocks = (cap_chunks + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n_cap, cuts_all, 0, digests_all, (unsigned long long*)ws, order, st);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

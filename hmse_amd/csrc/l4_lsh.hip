@@ -33,7 +33,8 @@ __device__ __forceinline__ uint32_t murmur3_words(const uint32_t* p, uint32_t nw
 }
 
 __global__ __launch_bounds__(256) void lsh_keys_kernel(const uint32_t* __restrict__ sig, uint64_t i0, uint64_t n, uint32_t bands,
-                                                        uint32_t rows, uint32_t* __restrict__ keys) {
+                                                        uint32_t rows, uint32_t* __restrict__ keys, const uint64_t* __restrict__ st = nullptr) {
+  if (st) { i0 = st[SB_U_OLD]; n = st[SB_U_NEW]; }
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * bands) return;
   g += i0 * bands;   // chunks [i0, i0 + n)
@@ -53,7 +54,8 @@ __device__ __forceinline__ bool band_equal(const uint32_t* sig, uint32_t nh, uin
 // one thread per (chunk, band): claim / lower the slot holding this band's content
 __global__ __launch_bounds__(256) void lsh_insert_kernel(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ keys,
                                                           uint64_t i0, uint64_t n, uint32_t bands, uint32_t rows, uint32_t* tables,
-                                                          uint32_t slots) {
+                                                          uint32_t slots, const uint64_t* __restrict__ st = nullptr) {
+  if (st) { i0 = st[SB_U_OLD]; n = st[SB_U_NEW]; }
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * bands) return;
   g += i0 * bands;   // chunks [i0, i0 + n) join tables that may already hold [0, i0)
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void lsh_insert_kernel(const uint32_t* __restr
 __global__ __launch_bounds__(256) void lsh_base_kernel(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ keys,
                                                         uint64_t i0, uint64_t n, uint32_t bands, uint32_t rows,
                                                         const uint32_t* __restrict__ tables, uint32_t slots,
-                                                        int64_t* __restrict__ base) {
+                                                        int64_t* __restrict__ base, const uint64_t* __restrict__ st = nullptr) {
+  if (st) { i0 = st[SB_U_OLD]; n = st[SB_U_NEW]; }
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
   const uint32_t i = (uint32_t)(i0 + i64), mask = slots - 1, nh = bands * rows;
@@ -162,5 +165,17 @@ extern "C" int hmse_l4_lsh_update(const uint32_t* sig_all, uint64_t n_old, uint6
                                                                                      (uint32_t)slots, base);
     HMSE_LAUNCH_CHECK();
   }
+  return HMSE_OK;
+}
+
+int hmse_l4_lsh_update_dyn(const uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* tables, uint64_t slots,
+                           const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream) {
+  if (!sig_all || !band_keys || !base_all || !tables || !st || slots < 1024 || (slots & (slots - 1)) || slots > (1ull << 24)) return HMSE_EINVAL;
+  const uint64_t nb = cap_chunks * cfg->bands;
+  lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig_all, 0, 0, cfg->bands, cfg->rows, band_keys, st);
+  lsh_insert_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig_all, band_keys, 0, 0, cfg->bands, cfg->rows, tables, (uint32_t)slots, st);
+  lsh_base_kernel<<<dim3((uint32_t)((cap_chunks + 255) / 256)), dim3(256), 0, stream>>>(sig_all, band_keys, 0, 0, cfg->bands, cfg->rows, tables, (uint32_t)slots,
+                                                                                       base_all, st);
+  HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

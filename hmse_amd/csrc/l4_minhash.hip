@@ -59,10 +59,11 @@ template <int NT, int V>
 __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                         const uint64_t* __restrict__ cuts,
                                                         const uint64_t* __restrict__ chunk_ids, uint64_t n_sel,
-                                                        uint32_t seed_base, uint32_t* __restrict__ sig) {
+                                                        uint32_t seed_base, uint32_t* __restrict__ sig, const uint64_t* __restrict__ st) {
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[MH_SLOTS];
   __shared__ uint32_t s_sig[NT / 64][128];
   __shared__ uint32_t s_flag;
+  if (st) { chunk_ids += st[SB_U_OLD]; sig += 128 * st[SB_U_OLD]; n_sel = st[SB_U_NEW]; }   // captured chain: this batch's stored chunks
   const uint64_t sel = blockIdx.x;
   if (sel >= n_sel) return;
   const uint32_t t = threadIdx.x, lane = lane_id(), w = t >> 6;
@@ -158,19 +159,28 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
   // variants 6 and 7 are timing probes that return WRONG signatures, which is why none of this is in the product library
   static const int variant = getenv("HMSE_MH_VARIANT") ? atoi(getenv("HMSE_MH_VARIANT")) : MH_DEFAULT_VARIANT;
   switch (variant) {
-    case 0: l4_minhash_kernel<256, 0><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
-    case 1: l4_minhash_kernel<256, 1><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
-    case 2: l4_minhash_kernel<512, 0><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
-    case 3: l4_minhash_kernel<512, 1><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
-    case 4: l4_minhash_kernel<1024, 0><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
-    case 6: l4_minhash_kernel<1024, 2><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;  // timing probe: no tail
-    case 7: l4_minhash_kernel<1024, 3><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;  // timing probe: no inserts
-    default: l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig); break;
+    case 0: l4_minhash_kernel<256, 0><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 1: l4_minhash_kernel<256, 1><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 2: l4_minhash_kernel<512, 0><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 3: l4_minhash_kernel<512, 1><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 4: l4_minhash_kernel<1024, 0><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 6: l4_minhash_kernel<1024, 2><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;  // timing probe: no tail
+    case 7: l4_minhash_kernel<1024, 3><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;  // timing probe: no inserts
+    default: l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
   }
 #else
-  l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig);
+  l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr);
 #endif
   PROF_END(HMSE_STAGE_L4_MINHASH, stream);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+// captured chain: one workgroup per POSSIBLE stored chunk of the batch; those beyond the device-side count leave at once
+int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
+                        const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream) {
+  if (!data || !cuts_all || !uniq_all || !sig_all || !st || cap_chunks == 0 || cap_chunks > 0x7FFFFFFFull) return HMSE_EINVAL;
+  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

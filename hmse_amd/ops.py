@@ -313,3 +313,27 @@ def manifest_pack(res, shard: int, n_shards: int, shard_bases, rec_off: torch.Te
     st = int(status.item())
     if st:
         raise HmseError(-2, f"hmse_manifest_pack device status {st:#x}")
+
+
+def stream_batch_workspace_bytes(batch_bytes: int, cfg: IngestConfig) -> int:
+    c = cfg.to_c()
+    return int(_lib.hip_lib().hmse_stream_batch_workspace_bytes(int(batch_bytes), C.byref(c)))
+
+
+def stream_batch(data: torch.Tensor, batch_bytes: int, seg_off: torch.Tensor, cfg: IngestConfig, state: torch.Tensor, cuts_all: torch.Tensor,
+                 max_chunks: int, digests_all: torch.Tensor, first_occ: torch.Tensor, refcount: torch.Tensor, l3_table: torch.Tensor,
+                 uniq_all: torch.Tensor, max_unique: int, sig_all: torch.Tensor, band_keys: torch.Tensor, base_all: torch.Tensor,
+                 lsh_tables: torch.Tensor, kind_all: torch.Tensor, stream_off_all: torch.Tensor, out: torch.Tensor, ws: torch.Tensor) -> None:
+    """hmse_stream_batch: the whole per-batch chain (L2 -> L3 -> index -> L4 -> band tables -> L1) enqueued without a host
+    read; capturable into a hipGraph (hmse_amd/stream.py).  README.md:1519-1580."""
+    for t, nm in ((data, "data"), (seg_off, "seg_off"), (state, "state"), (cuts_all, "cuts"), (digests_all, "digests"), (first_occ, "first_occ"),
+                  (refcount, "refcount"), (l3_table, "l3_table"), (uniq_all, "uniq"), (sig_all, "sig"), (band_keys, "band_keys"), (base_all, "base"),
+                  (lsh_tables, "lsh_tables"), (kind_all, "kind"), (stream_off_all, "stream_off"), (out, "out"), (ws, "ws")):
+        _require_gpu(t, nm)
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_batch(_ptr(data), data.numel(), int(batch_bytes), _ptr(seg_off), seg_off.numel() - 1, C.byref(c), _ptr(state),
+                                         _ptr(cuts_all), int(max_chunks), _ptr(digests_all), _ptr(first_occ), _ptr(refcount), _ptr(l3_table),
+                                         l3_table.numel(), _ptr(uniq_all), int(max_unique), _ptr(sig_all), _ptr(band_keys), _ptr(base_all),
+                                         _ptr(lsh_tables), lsh_tables.shape[1], _ptr(kind_all), _ptr(stream_off_all), _ptr(out), out.numel(),
+                                         ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_batch")

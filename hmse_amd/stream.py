@@ -21,7 +21,12 @@ from .ingest import ShardResult, shard_stats
 
 
 class StreamIngest:
-    def __init__(self, cfg: IngestConfig, capacity_bytes: int, device, max_chunks: int | None = None):
+    def __init__(self, cfg: IngestConfig, capacity_bytes: int, device, max_chunks: int | None = None, graph: bool = False,
+                 stream_capacity: int | None = None):
+        """graph=True: every batch runs as ONE enqueue of the device-count chain (hmse_stream_batch: no host read between
+        stages); from the second batch of a given size on, that enqueue is a replay of a hipGraph captured once for the size.
+        Results are identical to graph=False.  stream_capacity: bytes reserved for the DEFLATE streams in that mode
+        (default: half the corpus capacity + 64 MiB; overflow is reported, never written)."""
         if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
             raise ValueError("StreamIngest runs the full L1-L4 pipeline")
         self.cfg, self.dev = cfg, device
@@ -55,6 +60,12 @@ class StreamIngest:
         self.stream_bytes = 0
         self.stream_parts: list[torch.Tensor] = []
         self._ws = None             # DEFLATE workspace, kept across batches
+        self.graph = bool(graph)
+        if self.graph:
+            self._state = torch.zeros(16, dtype=torch.int64, device=device)
+            self._streams = torch.empty(int(stream_capacity or (capacity_bytes // 2 + (64 << 20))), dtype=torch.uint8, device=device)
+            self._graphs: dict[int, tuple] = {}     # batch bytes -> (CUDAGraph, workspace, seg_off) once captured; None after the eager first batch
+            self._state_dirty = True                # host counters -> device state before the next chain call
 
     # views of the filled part of the index
     cuts = property(lambda self: self._cuts[: self.n_chunks + 1])
@@ -76,7 +87,7 @@ class StreamIngest:
 
     @staticmethod
     def resume(m, cfg: IngestConfig, capacity_bytes: int, device, band_tables: bytes | None = None, verify: bool = True,
-               max_chunks: int | None = None) -> "StreamIngest":
+               max_chunks: int | None = None, graph: bool = False) -> "StreamIngest":
         """Incremental ingest against an existing store.  The raw bytes come back through the GPU read path
         (any stored chunk may become a dictionary); the INDEX is loaded, not recomputed: digests from the ChunkIndex records
         go straight into the L3 table, band keys and signatures from the band-table sidecar (index_sidecar()) go straight
@@ -86,7 +97,7 @@ class StreamIngest:
         import numpy as np
         from . import bandtable, read
         from .config import KIND_POINTER
-        st = StreamIngest(cfg, capacity_bytes, device, max_chunks)
+        st = StreamIngest(cfg, capacity_bytes, device, max_chunks, graph=graph)
         data = read.read_manifest(m, device, verify=verify)
         n = data.numel()
         if n % cfg.seg_size:
@@ -156,14 +167,63 @@ class StreamIngest:
     def finish(self) -> ShardResult:
         while self.pending:
             self._process(*self.pending.pop(0))
-        streams = torch.cat(self.stream_parts) if self.stream_parts else torch.empty(0, dtype=torch.uint8, device=self.dev)
+        if self.graph and not self._state_dirty:
+            self._read_state()
+            streams = self._streams[: self.stream_bytes]
+            if self.stream_parts:   # streams restored by resume() precede the chain's
+                streams = torch.cat(self.stream_parts + [self._streams[self._chain_s0: self.stream_bytes]])
+        else:
+            streams = torch.cat(self.stream_parts) if self.stream_parts else torch.empty(0, dtype=torch.uint8, device=self.dev)
         res = ShardResult(self.n_done, self.cuts, self.digests, 0, self.n_chunks, self.first_occ, self.refcount, self.uniq_ids,
                           self.sig, self.band_keys, self.base, streams, self.stream_off, self.kind)
         res.stats = shard_stats(res)
         return res
 
-    # ------------------------------------------------------------------ one batch
+    # ------------------------------------------------------------------ one batch, device-count chain (graph=True)
+    def _read_state(self) -> None:
+        """The ONE host read of the chain: counts after the batches enqueued so far."""
+        st = self._state.tolist()
+        if st[7]:
+            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bits 8.. DEFLATE "
+                             "(0x100 stream capacity, 0x200 workspace)")
+        self.n_done, self.n_chunks, self.n_unique, self.stream_bytes = st[0], st[1], st[3], st[5]
+
+    def _chain_call(self, n: int, seg_off: torch.Tensor, ws: torch.Tensor) -> None:
+        ops.stream_batch(self.data, n, seg_off, self.cfg, self._state, self._cuts, self.max_chunks, self._digests, self._first_occ, self._refcount,
+                         self._l3_table, self._uniq, self.max_unique, self._sig, self._band_keys, self._base, self._lsh_tables, self._kind,
+                         self._stream_off, self._streams, ws)
+
+    def _process_chain(self, off: int, n: int, copied: torch.cuda.Event) -> None:
+        dev = self.dev
+        if self._state_dirty:   # first chain call (possibly after resume()): host counters -> device state
+            self._chain_s0 = self.stream_bytes
+            if self.n_chunks == 0:
+                ops.l3_index_update(self._digests, 0, 0, self._first_occ, self._refcount, self._l3_table)      # clears the table
+                ops.l4_lsh_update(self._sig, 0, 0, self.cfg, self._band_keys, self._base, self._lsh_tables)     # clears the tables
+            self._state.copy_(torch.tensor([off, self.n_chunks, 0, self.n_unique, 0, self.stream_bytes] + [0] * 10, dtype=torch.int64))
+            self._state_dirty = False
+        torch.cuda.current_stream().wait_event(copied)
+        entry = self._graphs.get(n, 0)
+        if entry == 0:          # first batch of this size: plain enqueue (also sets the kernels' attributes before any capture)
+            seg_off = ops.segment_offsets(n, self.cfg.seg_size, dev)
+            ws = torch.empty(ops.stream_batch_workspace_bytes(n, self.cfg), dtype=torch.uint8, device=dev)
+            self._chain_call(n, seg_off, ws)
+            self._graphs[n] = (None, ws, seg_off)
+        else:
+            g, ws, seg_off = entry
+            if g is None:       # second batch of this size: capture the enqueue once ...
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._chain_call(n, seg_off, ws)
+                self._graphs[n] = (g, ws, seg_off)
+            g.replay()          # ... and from then on every batch of this size is one graph launch
+        self.n_done = off + n
+
+    # ------------------------------------------------------------------ one batch, host-sized launches (graph=False)
     def _process(self, off: int, n: int, copied: torch.cuda.Event) -> None:
+        if self.graph:
+            return self._process_chain(off, n, copied)
         cfg, dev = self.cfg, self.dev
         torch.cuda.current_stream().wait_event(copied)
         batch = self.data[off: off + n]

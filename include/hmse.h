@@ -251,6 +251,27 @@ int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* 
                        uint32_t* status, void* stream);
 
 /*
+ * One batch of the streaming front end as a single enqueue with NO host read (BASELINE.json configs[4]
+ * "hipGraph-captured per-batch pipeline"; the reference's batch loop README.md:1519-1580: request block -> L2 -> per chunk
+ * L3 lookup/insert -> L4 probe -> delta or full).  The batch's bytes are already at data[state[0] .. + batch_bytes); every
+ * stage takes its ranges from `state` (DEVICE u64[16]: [0] byte offset, [1] chunks so far, [2] chunks of this batch (out),
+ * [3] stored chunks so far, [4] stored chunks of this batch (out), [5] stream bytes so far, [6] stream bytes of this batch
+ * (out), [7] sticky status: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2 status, bits 8.. DEFLATE status), grids
+ * and workspace are sized for batch_bytes / min_size chunks, and the call ends by advancing [0], [1], [3], [5] — so the chain
+ * can be captured into a hipGraph once per batch size and replayed for every batch.  Appends to the per-chunk arrays of the
+ * stream (cuts_all, digests_all, first_occ, refcount, uniq_all, sig_all, band_keys, base_all, kind_all, stream_off_all), to the
+ * persistent L3 table / L4 band tables, and writes the batch's DEFLATE streams to out[state[5] ..).  seg_off DEVICE
+ * u64[n_seg+1]: batch-local segment offsets.  ws: hmse_stream_batch_workspace_bytes(batch_bytes, cfg).
+ */
+uint64_t hmse_stream_batch_workspace_bytes(uint64_t batch_bytes, const hmse_cfg* cfg);
+int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batch_bytes, const uint64_t* seg_off, uint32_t n_seg,
+                      const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks, uint8_t* digests_all,
+                      uint64_t* first_occ, uint32_t* refcount, uint32_t* l3_table, uint64_t l3_slots, uint64_t* uniq_all,
+                      uint64_t max_unique, uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* lsh_tables,
+                      uint64_t lsh_slots, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out, uint64_t out_cap,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/*
  * Chunk manifest — the packed on-disk records, written on the GPU (README.md:1263-1270 ChunkIndex 40 B, 2182-2189
  * DeltaChunk 8-byte header + delta data, 1312 pointer 8 B, 1448 per-chunk map, 1635-1669 chunk types).  Replaces the
  * reference's per-chunk "write chunk, insert (sha -> lba, len)" / "pointer record, refcount++" steps of the batch loop

@@ -123,3 +123,39 @@ def test_resume_loads_the_index_from_chunkindex_and_band_table_sidecar(dev):
     assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))
     with pytest.raises(ValueError):
         stream.StreamIngest.resume(manifest.Manifest.from_bytes(blob), cfg, data.size, dev, band_tables=bandtable.write_band_tables(keys[:5], 16, sig[:5]))
+
+
+def test_captured_chain_equals_eager_and_one_shot(dev):
+    """BASELINE configs[4] "hipGraph-captured per-batch pipeline": with graph=True every batch is ONE enqueue of the
+    device-count chain (no host read between stages); the first batch of a size is enqueued directly, the second is
+    captured into a hipGraph, the third and later ones replay it.  Every output equals the host-sized eager path and one
+    ingest of the whole stream, bit for bit — also across a batch of a different size and after resume()."""
+    import torch
+    from hmse_amd import IngestConfig, ingest, manifest, read, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    names = ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams")
+    B = 2 << 20
+    for graph in (True, False):
+        st = stream.StreamIngest(cfg, data.size, dev, graph=graph)
+        for a in range(0, data.size, B):
+            st.push(torch.from_numpy(data[a: a + B].copy()))
+        res = st.finish()
+        for name in names:
+            assert torch.equal(getattr(res, name), getattr(whole, name)), (graph, name)
+        if graph:
+            sizes = {k: (v[0] is not None) for k, v in st._graphs.items()}
+            assert sizes[B] is True and len(sizes) == 2          # the common size was captured and replayed; the ragged tail ran directly
+            assert torch.equal(read.reconstruct_shard(res, verify=True), torch.from_numpy(data).to(dev))
+    # resume() + captured chain
+    split = 6 << 20
+    first = ingest.ingest_shard(torch.from_numpy(data[:split]).to(dev), cfg)
+    m = manifest.Manifest.from_bytes(manifest.build_manifest(first).to_bytes())
+    del first
+    st = stream.StreamIngest.resume(m, cfg, data.size, dev, graph=True)
+    for a in range(split, data.size, 1 << 20):
+        st.push(torch.from_numpy(data[a: a + (1 << 20)].copy()))
+    res = st.finish()
+    for name in names:
+        assert torch.equal(getattr(res, name), getattr(whole, name)), ("resume", name)

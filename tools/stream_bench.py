@@ -12,6 +12,7 @@ bat = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024) << 20
 profiles = (sys.argv[3] if len(sys.argv) > 3 else "wikipedia").split(",")
 dev = torch.device("cuda:0")
 cfg = IngestConfig()
+GRAPH = os.environ.get("STREAM_GRAPH") == "1"   # every batch = one enqueue of the device-count chain, replayed from a hipGraph
 per = tot // len(profiles) // cfg.seg_size * cfg.seg_size
 t0 = time.perf_counter()
 host = torch.empty(per * len(profiles), dtype=torch.uint8).pin_memory()
@@ -20,7 +21,7 @@ for i, p in enumerate(profiles):
 tot = host.numel()
 print(f"corpus: {len(profiles)} x {per / 1e9:.2f} GB ({', '.join(profiles)}) generated and pinned in {time.perf_counter() - t0:.1f} s", flush=True)
 # warm-up outside the clock: module load, kernel attributes, allocator (a 16 GiB run's first iteration carries ~1.8 s of it)
-w = stream.StreamIngest(cfg, 512 << 20, dev)
+w = stream.StreamIngest(cfg, 512 << 20, dev, graph=GRAPH)
 for a in range(0, 512 << 20, 128 << 20):
     w.push(host[a: a + (128 << 20)])
 w.finish(); del w
@@ -28,7 +29,7 @@ torch.cuda.synchronize()
 iters = 2 if tot <= (16 << 30) else 1
 for it in range(iters):
     torch.cuda.synchronize(); tc = time.perf_counter()
-    st = stream.StreamIngest(cfg, tot, dev)          # one-time: the resident corpus buffer, the index arrays and tables
+    st = stream.StreamIngest(cfg, tot, dev, graph=GRAPH)          # one-time: the resident corpus buffer, the index arrays and tables
     torch.cuda.synchronize(); t0 = time.perf_counter()
     print(f"  index + corpus buffer allocated in {(t0 - tc) * 1e3:.0f} ms (outside the clock)", flush=True)
     per_batch = []
@@ -42,7 +43,7 @@ for it in range(iters):
         print("  ms per push (batch k's copy + batch k-1's kernels, synchronised):", per_batch, flush=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = res.stats
-    print(f"stream iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
+    print(f"stream{" [hipGraph chain]" if GRAPH else ""} iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
           f"CF {tot / (s['stored_bytes'] + 40 * s['unique'] + 8 * s['pointer'] + 8 * s['delta']):.3f}  chunks {s['chunks']}  unique {s['unique']}  "
           f"delta {s['delta']}  HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     del st, res
