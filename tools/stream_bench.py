@@ -12,7 +12,8 @@ bat = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024) << 20
 profiles = (sys.argv[3] if len(sys.argv) > 3 else "wikipedia").split(",")
 dev = torch.device("cuda:0")
 cfg = IngestConfig()
-GRAPH = os.environ.get("STREAM_GRAPH") == "1"   # every batch = one enqueue of the device-count chain, replayed from a hipGraph
+GRAPH = os.environ.get("STREAM_GRAPH") == "1"
+TAG = " [hipGraph chain]" if GRAPH else ""   # every batch = one enqueue of the device-count chain, replayed from a hipGraph
 per = tot // len(profiles) // cfg.seg_size * cfg.seg_size
 t0 = time.perf_counter()
 host = torch.empty(per * len(profiles), dtype=torch.uint8).pin_memory()
@@ -43,7 +44,7 @@ for it in range(iters):
         print("  ms per push (batch k's copy + batch k-1's kernels, synchronised):", per_batch, flush=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = res.stats
-    print(f"stream{" [hipGraph chain]" if GRAPH else ""} iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
+    print(f"stream{TAG} iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
           f"CF {tot / (s['stored_bytes'] + 40 * s['unique'] + 8 * s['pointer'] + 8 * s['delta']):.3f}  chunks {s['chunks']}  unique {s['unique']}  "
           f"delta {s['delta']}  HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     del st, res
