@@ -234,8 +234,10 @@ def test_distributed_ingest_world_size_1_runs_rccl(dev):
     cfg = IngestConfig(seg_size=1 << 20)
     data = torch.from_numpy(corpus.wiki_synth(3 << 20, seed=42)).to(dev)
     ref = ingest.ingest_shard(data, cfg)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
