@@ -633,7 +633,10 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
                       else if (pa + run > p) m = (pa + run - p) < maxlen ? (pa + run - p) : maxlen;
                       if (m > bm) { bm = m; bq = p - d; }
                     }
-                    if (bm >= 16u && (uint32_t)S[i - kmax] <= bq) ph = bq | (bm << 16);
+                    // a hint of the full length min(258, T - p) is TAKEN by definition when the walk leaves the chunk (rule 2b of
+                    // the oracle): bit 31.  A shorter one only spares the byte compare of a candidate the walk reaches anyway.
+                    if (bm >= 16u && bm == maxlen) ph = bq | (bm << 16) | 0x80000000u;
+                    else if (bm >= 16u && (uint32_t)S[i - kmax] <= bq) ph = bq | (bm << 16);
 #ifdef HMSE_DFL_STAMPS
                     if (t == 0) { stamp_acc[6]++; if (bm >= 16u) stamp_acc[7]++; if (ph) stamp_acc[8]++; }  // lane 0's positions: fetched / hinted / usable
 #endif
@@ -656,23 +659,25 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             bd |= 0x80000000u;
             // with a hint, candidate q' (farther on in this walk) is known to reach ph >> 16 bytes: a nearer dictionary candidate
             // only matters if it reaches as many (it then wins the tie), so the filters may already work with that length
-            if (DICT && ph && (ph >> 16) - 1u > best) { best = (ph >> 16) - 1u; probe = ld32a(W, p + best - 3); }
+            if (DICT && (ph >> 31)) q = ph & 0xFFFFu;   // full-length hint: the walk's dictionary part IS this one candidate
+            else if (DICT && ph && ((ph >> 16) & 0x7FFFu) - 1u > best) { best = ((ph >> 16) & 0x7FFFu) - 1u; probe = ld32a(W, p + best - 3); }
           }
           // a candidate the byte-4 filter rejects (37 % of them on text) is consumed on the spot and the next one takes
           // its place in this trip: the filter needs nothing but the two prefetched values
           // (classes with the filter array only: where byte 4 is a dependent window read the second test costs more than it saves)
-          if (!NOK && best >= 4 && kb != (pw1 & 0xFFu) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX)) {
+          if (!NOK && best >= 4 && kb != (pw1 & 0xFFu) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX) && !(DICT && (ph >> 31) && q == (ph & 0xFFFFu))) {
             kk++;
             q = qn; kb = kn;
             if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }
             if (variant && q < Dl && !(bd >> 31)) {
               if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
               bd |= 0x80000000u;
-              if (DICT && ph && (ph >> 16) - 1u > best) { best = (ph >> 16) - 1u; probe = ld32a(W, p + best - 3); }
+              if (DICT && (ph >> 31)) q = ph & 0xFFFFu;
+              else if (DICT && ph && ((ph >> 16) & 0x7FFFu) - 1u > best) { best = ((ph >> 16) & 0x7FFFu) - 1u; probe = ld32a(W, p + best - 3); }
             }
           }
           fin = true; ml = 0;
-          if (DICT && ph && q == (ph & 0xFFFFu)) ml = ph >> 16;        // the hinted candidate: its length is known, no byte is read
+          if (DICT && ph && q == (ph & 0xFFFFu) && ((bd >> 31) || !(ph >> 31))) ml = (ph >> 16) & 0x7FFFu;  // the hinted candidate: its length is known, no byte is read
           else if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;        // farther ones are farther still
           else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
           else {
@@ -721,7 +726,11 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (++kk > kmax) pos_done = true;
           st = PROBE;
           if (pos_done) {
-            if (best >= MINM) {
+            if (DICT && (ph >> 31) && !(bd >> 31) && best < maxlen) {
+              // depth used up inside the chunk while a full-length hint is pending: FULL = what the walk holds, DELTA = the hint
+              if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
+              mlen[p - Dl] = (uint8_t)(maxlen - 3); mdist[p - Dl] = (uint16_t)(p - (ph & 0xFFFFu));
+            } else if (best >= MINM) {
               mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd;
               if (variant && !(bd >> 31)) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }  // never reached the dictionary
             }

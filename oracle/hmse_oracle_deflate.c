@@ -14,6 +14,19 @@
  *  2. For every chunk position p (p+4 <= T): walk the bucket backwards from p's predecessor,
  *     at most D candidates, stop at distance > 32768; ml = common prefix capped at
  *     min(258, T-p); keep the longest (first found wins ties); accept iff >= 4.
+ *  2b. Dictionary jobs only (Dl > 0) — diagonal anchors.  A chunk with an LSH base is a near-duplicate
+ *     of it, so most positions have a full-length match in the dictionary on the same diagonal as
+ *     their neighbours.  Every 64th chunk position pa = Dl + 64a (pa+4 <= T) is an ANCHOR: among
+ *     the (at most) 64 nearest dictionary members of its bucket within distance 32768, the one
+ *     agreeing with pa on most of the next 32 bytes (window padded with zeros; ties: nearest), if
+ *     all 32 agree, gives the anchor's distance d, and run = number of x < min(512, T-pa) with
+ *     W[pa+x] == W[pa+x-d] for all smaller x too (the run along the diagonal).  A position p in
+ *     block a takes a HINT from anchor a, else a-1: q' = p-d must lie in the dictionary, its known
+ *     common prefix with p is m = min(258, T-p) if run = 512, else min(pa+run-p, 258, T-p) if
+ *     pa+run > p; the longer hint wins (anchor a on ties).  If m >= 16 and m = min(258, T-p), the
+ *     walk of rule 2 ends when it leaves the chunk: unless a chunk candidate already reached the
+ *     full length, the match is (m, p-q').  Otherwise rule 2 applies unchanged.
+ *     (The FULL encoding of the same chunk — chunk candidates only — is never affected.)
  *  3. Parse from p = Dl: take the match at p iff mlen[p] >= 4 and not (mlen[p+1] > mlen[p]);
  *     otherwise emit the literal and move to p+1 (one-step lazy evaluation, like deflate_slow).
  *  4. One final block: stored / fixed / dynamic, whichever is smallest in bits
@@ -64,10 +77,10 @@ static void lz_build(lz_t* z, const uint8_t* chunk, uint32_t len, const uint8_t*
   if (dlen > WMAX) { dict += dlen - WMAX; dlen = WMAX; }
   uint32_t T = dlen + len;
   z->T = T; z->Dl = dlen;
-  z->W = (uint8_t*)malloc(T + 8);
+  z->W = (uint8_t*)malloc(T + 64);
   if (dlen) memcpy(z->W, dict, dlen);
   if (len) memcpy(z->W + dlen, chunk, len);
-  memset(z->W + T, 0, 8);
+  memset(z->W + T, 0, 64);
   z->mlen = (uint16_t*)calloc(len + 1, 2);
   z->mdist = (uint16_t*)calloc(len + 1, 2);
   uint32_t nh = T >= 4 ? T - 3 : 0; /* positions with a 4-byte hash */
@@ -83,21 +96,69 @@ static void lz_build(lz_t* z, const uint8_t* chunk, uint32_t len, const uint8_t*
     S[r] = (uint16_t)q; rank[q] = r;
   }
   uint32_t D = depth_from_cfg(cfg);
+  /* rule 2b: anchors of a dictionary job */
+  uint32_t n_anch = dlen ? (len + 63) / 64 : 0;
+  uint32_t* anch_d = (uint32_t*)calloc(n_anch + 1, 4);
+  uint32_t* anch_run = (uint32_t*)calloc(n_anch + 1, 4);
+  for (uint32_t a = 0; a < n_anch; a++) {
+    uint32_t pa = dlen + 64 * a;
+    if (pa + 4 > T) continue;
+    uint32_t h = hash4(le32(z->W + pa));
+    uint32_t lo = start[h], hi = start[h + 1];
+    uint32_t l = lo;                                   /* dictionary members are the first ones of the bucket */
+    while (l < hi && S[l] < dlen) l++;
+    uint32_t first = l > lo + 64 ? l - 64 : lo;
+    uint32_t bml = 0, bq = 0;
+    for (uint32_t idx = first; idx < l; idx++) {         /* ascending position: a later one is nearer and wins ties */
+      uint32_t q = S[idx];
+      if (pa - q > WMAX) continue;
+      uint32_t ml = 0;
+      while (ml < 32 && z->W[q + ml] == z->W[pa + ml]) ml++;   /* (W is zero-padded behind T) */
+      if (ml >= bml) { bml = ml; bq = q; }
+    }
+    if (bml >= 32) {
+      uint32_t d = pa - bq, lim = T - pa < 512 ? T - pa : 512, run = 0;
+      while (run < lim && z->W[pa + run] == z->W[pa + run - d]) run++;
+      anch_d[a] = d; anch_run[a] = run;
+    }
+  }
   for (uint32_t p = dlen; p < T; p++) {
     if (p + 4 > T) continue;
     uint32_t h = hash4(le32(z->W + p));
     uint32_t r = rank[p], g = start[h];
     uint32_t maxlen = T - p < MAXM ? T - p : MAXM;
     uint32_t best = MINM - 1, bdist = 0;
+    /* hint of rule 2b */
+    uint32_t hm = 0, hq = 0;
+    if (dlen) {
+      uint32_t a0 = (p - dlen) >> 6;
+      for (uint32_t back = 0; back < 2; back++) {
+        if (a0 < back) continue;
+        uint32_t d = anch_d[a0 - back], run = anch_run[a0 - back], pa = dlen + ((a0 - back) << 6);
+        if (d == 0 || d > p || p - d >= dlen) continue;
+        uint32_t m = 0;
+        if (run >= 512) m = maxlen;
+        else if (pa + run > p) m = pa + run - p < maxlen ? pa + run - p : maxlen;
+        if (m > hm) { hm = m; hq = p - d; }
+      }
+    }
+    int full_hint = hm >= 16 && hm == maxlen;
+    int resolved = 0;
     for (uint32_t k = 1; k <= D && r >= g + k; k++) {
       uint32_t q = S[r - k];
       if (p - q > WMAX) break;
+      if (full_hint && q < dlen) {                       /* the walk leaves the chunk: the hinted match is taken */
+        best = hm; bdist = p - hq; resolved = 1;
+        break;
+      }
       uint32_t ml = 0;
       while (ml < maxlen && z->W[q + ml] == z->W[p + ml]) ml++;
-      if (ml > best) { best = ml; bdist = p - q; if (ml == maxlen) break; }
+      if (ml > best) { best = ml; bdist = p - q; if (ml == maxlen) { resolved = 1; break; } }
     }
+    if (full_hint && !resolved) { best = hm; bdist = p - hq; }   /* (depth used up inside the chunk, or distance limit) */
     if (best >= MINM) { z->mlen[p - dlen] = (uint16_t)best; z->mdist[p - dlen] = (uint16_t)bdist; }
   }
+  free(anch_d); free(anch_run);
   free(start); free(fill); free(S); free(rank);
 }
 

@@ -164,8 +164,41 @@ def _dist_code(dist):
     raise ValueError(dist)
 
 
+def lz_anchors(w: bytes, dl: int, buckets: dict) -> dict:
+    """Rule 2b, first half: block a of a dictionary job's chunk -> (distance, run) of its anchor position dl + 64 a."""
+    t = len(w)
+    padded = w + bytes(64)
+    out = {}
+    for a in range((t - dl + 63) // 64):
+        pa = dl + 64 * a
+        if pa + 4 > t:
+            continue
+        h = ((int.from_bytes(w[pa:pa + 4], "little") * 0x9E3779B1) & M32) >> 20
+        near = [q for q in buckets.get(h, []) if q < dl][-64:]          # the nearest 64 dictionary members
+        score = {}
+        for q in near:
+            if pa - q > 32768:
+                continue
+            n = 0
+            while n < 32 and padded[q + n] == padded[pa + n]:
+                n += 1
+            score[q] = n
+        if not score:
+            continue
+        top = max(score.values())
+        if top < 32:
+            continue
+        q = max(q for q, n in score.items() if n == top)                  # ties: nearest
+        d, run = pa - q, 0
+        while run < min(512, t - pa) and w[pa + run] == w[pa + run - d]:
+            run += 1
+        out[a] = (d, run)
+    return out
+
+
 def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
-    """Rules 1-2: per chunk position the longest match among its `depth` nearest bucket predecessors."""
+    """Rules 1-2b: per chunk position the longest match among its `depth` nearest bucket predecessors; in a dictionary job a
+    position inside an anchor's full-length diagonal run takes that match when its walk leaves the chunk."""
     dict_ = dict_[-32768:]
     w = dict_ + chunk
     t, dl = len(w), len(dict_)
@@ -177,13 +210,29 @@ def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
     for members in buckets.values():
         for r, q in enumerate(members):
             where[q] = (members, r)
+    anchors = lz_anchors(w, dl, buckets) if dl else {}
     mlen, mdist = [0] * len(chunk), [0] * len(chunk)
     for p in range(dl, t - 3):
         members, r = where[p]
         cap = min(258, t - p)
-        best, bdist = 3, 0
+        hint = (0, 0)                                                     # (known length, candidate position)
+        for a in ((p - dl) // 64, (p - dl) // 64 - 1):
+            if a < 0 or a not in anchors:
+                continue
+            d, run = anchors[a]
+            pa = dl + 64 * a
+            if d > p or p - d >= dl:
+                continue
+            m = cap if run >= 512 else (min(pa + run - p, cap) if pa + run > p else 0)
+            if m > hint[0]:
+                hint = (m, p - d)
+        full = hint[0] >= 16 and hint[0] == cap
+        best, bdist, resolved = 3, 0, False
         for q in reversed(members[max(0, r - depth):r]):   # nearest first
             if p - q > 32768:
+                break
+            if full and q < dl:                            # leaving the chunk: the hinted match is taken
+                best, bdist, resolved = hint[0], p - hint[1], True
                 break
             n = 0
             while n < cap and w[q + n] == w[p + n]:
@@ -191,7 +240,10 @@ def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
             if n > best:
                 best, bdist = n, p - q
                 if n == cap:
+                    resolved = True
                     break
+        if full and not resolved:
+            best, bdist = hint[0], p - hint[1]
         if best >= 4:
             mlen[p - dl], mdist[p - dl] = best, bdist
     return mlen, mdist

@@ -301,6 +301,23 @@ def test_deflate_c_oracle_equals_python_restatement(orc):
             want, got = orc.deflate(c, cfg, d), pyref.deflate(c, d, chain_depth=kw.get("chain_depth", 0))
             assert want == got, (len(c), len(d), kw)
             assert _rt(got, d) == c
+    # dictionary jobs with insertions / deletions / substitutions: several diagonals, anchors and hints of rule 2b
+    base = words_text(7000, seed=9).tobytes()
+    erng = np.random.default_rng(3)
+    for trial in range(6):
+        v = bytearray(base)
+        for _ in range(int(erng.integers(1, 6))):
+            pos = int(erng.integers(0, len(v) - 50)); kind = int(erng.integers(0, 3))
+            if kind == 0:
+                v[pos:pos] = bytes(erng.integers(97, 123, int(erng.integers(1, 40)), dtype=np.uint8))
+            elif kind == 1:
+                del v[pos:pos + int(erng.integers(1, 40))]
+            else:
+                v[pos] = 63
+        v = bytes(v)
+        want, got = orc.deflate(v, orc.default_cfg(), base), pyref.deflate(v, base)
+        assert want == got, trial
+        assert _rt(got, base) == v and len(got) * 6 < len(v)
     ml, md = orc.deflate_matches(text[:2500].encode() if isinstance(text, str) else text[:2500], orc.default_cfg())
     pl, pd = pyref.lz_matches(text[:2500], b"", 32)
     assert ml.tolist() == pl and md.tolist() == pd
