@@ -33,6 +33,7 @@ struct Args {
   const uint8_t* kind; const int64_t* base; uint32_t n_sel;
   const uint64_t* raw_off; uint8_t* raw_out; uint64_t raw_cap;
   uint32_t* status; uint8_t* ok; uint32_t* done; uint32_t* counter;
+  uint32_t dflags;  // diagnostics only (HMSE_DIAG build): 1 = skip literal stores, 2 = skip match stores, 4 = skip match loads
   uint32_t* trace;  // diagnostics only (tools/inflate_debug.py): host-visible progress words, 8 per wavefront
 };
 
@@ -324,6 +325,483 @@ __global__ __launch_bounds__(NT, 8) void l1_inflate_kernel(Args a) {
   IFL_TRACE(0, 9);
 }
 
+}  // namespace ifl
+
+// =====================================================================================================================
+// ONE STREAM PER LANE (the wide kernel, taken when a call carries enough streams to fill the chip's lanes).
+//
+// The wavefront-per-stream kernel above keeps 63 lanes waiting on one scalar bit reader: per token it issues ~100
+// scalar and ~45 vector instructions, and the CU's single scalar unit is what bounds it (profiles/r2: 2.25 scalar
+// per vector instruction, VALU half idle).  Here every lane is a complete, independent DEFLATE decoder: 64 streams per
+// wavefront, no cross-lane operation in the data path at all.  What makes that fit the machine:
+//   * canonical Huffman decode WITHOUT a length loop or a lookup table: for each code length l the table build leaves a
+//     packed word  limit_l << 16 | info  in a REGISTER (limit_l = left-aligned end of the codes of length <= l).  The
+//     next 15 stream bits, bit-reversed, are compared with all 15 words (v_cmp + v_cndmask each, fully unrolled, static
+//     register indices): the last word not above the bits carries the code's length, the first code of that length and
+//     the offset of its symbols.  One LDS byte read then gives the symbol.
+//   * per-lane tables in LDS, lane-interleaved words (word w of lane l at w*64+l: conflict-free when lanes touch the same
+//     word index): 288 literal/length symbol bytes (bit 8 of a symbol comes from comparing its index with the count of
+//     literals of that length), 32 distance symbols, 320 code-length nibbles, per-length running offsets: 576 B per lane,
+//     36 KiB per wavefront, four wavefronts per CU = 256 streams in flight per CU, 65 536 on the chip;
+//   * a state machine per lane, one micro-step per loop trip: decode a token / copy up to 16 bytes of a match.  Match
+//     sources are loaded one trip before they are stored (two 8-byte loads, the stores sized by overlapping 8/4-byte
+//     pieces), the bit window is refilled from an 8-byte word loaded one trip ahead, so no trip waits on HBM/L2;
+//     a self-overlapping match doubles its copy distance (a multiple of dist) until 16 bytes fit;
+//   * block headers (code-length code, length decode, table build: ~15 k instructions per lane) would run with one or
+//     two lanes active if each lane did them when it got there.  Lanes that need a header WAIT until 16 of them do (or
+//     nothing else can run), then go through it together;
+//   * a DELTA stream whose base is not decoded yet builds its tables and then polls the base's flag once per trip
+//     (never a spin: the base may be another lane of this very wavefront).
+// Every wait is bounded (symbol budget per stream, poll budget per base, bytes per copy), so every lane reaches DONE.
+namespace ifl {
+
+constexpr int LW = 144;                         // LDS words per lane
+constexpr int W_LSYM = 0, W_DSYM = 72, W_LENS = 80, W_CL = 120, W_NLO = 128, W_CD = 136;
+constexpr uint32_t ST_WAIT = 0, ST_DEC = 1, ST_FIN = 2, ST_DONE = 3;
+constexpr uint32_t HDR_MIN = 16;                // lanes that must be waiting before a header round is run
+constexpr uint32_t POLL_MAX = 1u << 21;
+
+__device__ __forceinline__ uint64_t load8_at(const uint8_t* base, uint64_t off, uint64_t total) {
+  uint64_t w = 0;
+  if (off + 8 <= total) __builtin_memcpy(&w, base + off, 8);
+  else for (uint32_t j = 0; j < 8; j++) if (off + j < total) w |= (uint64_t)base[off + j] << (8 * j);
+  return w;
+}
+
+// length of the code that the left-aligned 15-bit value X starts with, and where its symbols are:
+// T[j] = limit_j << 16 | info, ascending in j; the last entry with limit_j <= X wins (T[0] has limit 0)
+#define IFL_SCAN(X, T, NL, sel)                                        \
+  do {                                                                 \
+    const uint32_t xk_ = ((X) << 16) | 0xFFFFu;                        \
+    sel = T[0];                                                        \
+    _Pragma("unroll") for (int j_ = 1; j_ <= NL; j_++) sel = xk_ >= T[j_] ? T[j_] : sel; \
+  } while (0)
+
+#ifdef HMSE_DIAG
+// cycle shares of the trip's steps, summed over wavefronts into a.trace as u64[8] (tools/inflate_lanes_cycles.py):
+// trips, header rounds, cycles in publish / header / poll / decode / memory cluster, lane-trips that decoded a token
+#define LK_T0() uint64_t t_ = __builtin_readcyclecounter()
+#define LK_LAP(i) do { const uint64_t u_ = __builtin_readcyclecounter(); cyc[i] += u_ - t_; t_ = u_; } while (0)
+#else
+#define LK_T0() do { } while (0)
+#define LK_LAP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
+  __shared__ uint32_t lds[LW * 64];
+  const uint32_t lane = threadIdx.x;
+  uint32_t* const my = lds + lane;                                    // word w at my[w * 64]
+  uint8_t* const myb = (uint8_t*)lds + lane * 4;                      // byte B at myb[(B >> 2) * 256 + (B & 3)]
+#define LB(B) myb[(((uint32_t)(B)) >> 2) * 256u + (((uint32_t)(B)) & 3u)]
+
+  uint32_t P[16], Q[16], PD[16];                                      // decode words of the current block (see IFL_SCAN)
+#pragma unroll
+  for (int j = 0; j < 16; j++) { P[j] = 0; Q[j] = 0; PD[j] = 0; }
+  uint32_t st = ST_WAIT;
+  bool pass2 = false;
+  bool need_pull = true, bad = false, last = false, eob = false, blocked = false, stored = false;
+  uint32_t k = 0, L = 0, pos = 0, Dl = 0, budget = 0, polls = 0, n = 0;
+  uint64_t bidx = 0, acc = 0, p = 0, end = 0, wnext = 0, sp = 0;
+  uint8_t* outp = a.raw_out;
+  const uint8_t* dictp = a.raw_out;
+  uint32_t rem = 0, cq = 0, D = 1, span = 0;                          // match / stored-block copy in progress
+  uint32_t pn = 0, pdst = 0; uint64_t pc0 = 0, pc1 = 0;               // bytes loaded last trip, stored this trip
+  uint32_t wsh = 0, pback = 0;                                        // fix-ups of loads pulled back from a buffer's end
+  uint32_t lit = 0;                                                   // 0x100 | literal decoded this trip
+
+#ifdef HMSE_DIAG
+  uint64_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  for (uint32_t trip = 0; trip < 0x7FFFFFF0u; trip++) {
+    LK_T0();
+#ifdef HMSE_DIAG
+    cyc[0]++;
+#endif
+    // ---- 1. publish finished streams -----------------------------------------------------------------------------
+    if (__ballot(st == ST_FIN)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (st == ST_FIN) {
+        __hip_atomic_store(&a.done[k], bad ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.ok) a.ok[k] = bad ? 0 : 1;
+        if (bad) atomicOr(a.status, 1u);
+        st = ST_WAIT; need_pull = true;
+      }
+    }
+    LK_LAP(2);
+    // ---- 2. header round ---------------------------------------------------------------------------------------------
+    const uint32_t n_wait = (uint32_t)__builtin_popcountll(__ballot(st == ST_WAIT));
+    const uint64_t m_run = __ballot(st == ST_DEC && !blocked);
+    if (n_wait >= HDR_MIN || (n_wait != 0 && m_run == 0)) {
+#ifdef HMSE_DIAG
+      cyc[1]++;
+#endif
+      if (st == ST_WAIT) {
+        if (need_pull) {
+          // two passes over the records inside one launch: first everything that needs no dictionary, then the DELTA
+          // records — whose bases are then decoded already (or, for a chain of DELTAs and at the seam of the passes, were
+          // pulled earlier and are being decoded).  In plain index order a DELTA record sits right behind its base (near-
+          // duplicates are neighbours) and its lane idled for the whole of the base's decode: 22 of 64 lanes on average.
+          for (;;) {
+            if (!pass2) {
+              k = atomicAdd(a.counter, 1u);
+              if (k >= a.n_sel) { pass2 = true; continue; }
+              if (a.kind[k] == HMSE_KIND_DELTA) continue;
+            } else {
+              k = atomicAdd(a.counter + 1, 1u);
+              if (k >= a.n_sel) { st = ST_DONE; break; }
+              if (a.kind[k] != HMSE_KIND_DELTA) continue;
+            }
+            break;
+          }
+          if (st != ST_DONE) {
+            need_pull = false;
+            const uint64_t o0 = a.raw_off[k], o1 = a.raw_off[k + 1];
+            L = (uint32_t)(o1 - o0);
+            outp = a.raw_out + o0;
+            bad = o1 < o0 || o1 > a.raw_cap || o1 - o0 > 0x7FFFFFFFull;
+            blocked = false; dictp = a.raw_out; Dl = 0; polls = 0;
+            if (!bad && a.kind[k] == HMSE_KIND_DELTA) {
+              const int64_t b = a.base ? a.base[k] : -1;
+              if (b < 0 || (uint64_t)b >= k) bad = true;
+              else { blocked = true; bidx = (uint64_t)b; }
+            }
+            const uint64_t s0 = a.stream_off[k];
+            const uint64_t s1 = a.stream_len ? s0 + a.stream_len[k] : a.stream_off[k + 1];
+            if (s1 < s0 || s1 > a.streams_bytes) bad = true;
+            p = s0; end = bad ? s0 : s1; acc = 0; n = 0; pos = 0; last = false; eob = false;
+            rem = 0; pn = 0;
+            const uint64_t bits = 8ull * (end - s0) + 64;
+            budget = bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)bits;
+          }
+        }
+        if (st == ST_WAIT && bad) st = ST_FIN;
+        if (st == ST_WAIT) {
+          // -- block header (RFC 1951 §3.2.3) --
+#define HREFILL() do { const uint64_t w_ = load8_at(a.streams, p, a.streams_bytes); acc |= w_ << n; const uint32_t adv_ = (63u - n) >> 3; p += adv_; n += adv_ * 8u; } while (0)
+#define HTAKE(kk, dst) do { if (n < (kk)) HREFILL(); dst = (uint32_t)acc & ((1u << (kk)) - 1u); acc >>= (kk); n -= (kk); } while (0)
+          if (budget-- == 0) bad = true;
+          uint32_t hdr; HTAKE(3, hdr);
+          last = (hdr & 1u) != 0;
+          const uint32_t type = hdr >> 1;
+          eob = false;
+          if (bad) {
+          } else if (type == 3) bad = true;
+          else if (type == 0) {  // stored
+            const uint32_t sk = n & 7u; acc >>= sk; n -= sk;
+            uint32_t len, nlen; HTAKE(16, len); HTAKE(16, nlen);
+            const uint64_t src = p - (n >> 3);
+            if ((len ^ nlen) != 0xFFFFu || pos + len > L || src + len > end) bad = true;
+            else {
+              stored = true; sp = src; rem = len; cq = pos; pos += len;
+              p = src + len; acc = 0; n = 0; eob = true;
+            }
+          } else {
+            uint32_t nlit = 288, ndist = 32;
+            const bool fixed = type == 1;
+            uint32_t PC[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) PC[j] = 0;
+            if (!fixed) {
+              uint32_t t5; HTAKE(5, t5); nlit = t5 + 257; HTAKE(5, t5); ndist = t5 + 1;
+              uint32_t ncl; HTAKE(4, ncl); ncl += 4;
+              if (nlit > 286 || ndist > 30) bad = true;
+              uint64_t cl57 = 0;   // code-length code lengths, 3 bits per symbol
+              for (uint32_t i = 0; i < ncl; i++) {
+                uint32_t v; HTAKE(3, v);
+                // order of the code-length code lengths (RFC 1951 §3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                const uint32_t o = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) >> 1 : 6 + (i >> 1);
+                cl57 |= (uint64_t)v << (3 * o);
+              }
+              uint64_t cnt8 = 0;   // symbols per length, 8-bit fields
+              for (uint32_t s = 0; s < 19; s++) { const uint32_t l = (uint32_t)(cl57 >> (3 * s)) & 7u; cnt8 += 1ull << (8 * l); }
+              // limits and offsets per length; the code-length code must be complete (or empty), as stock zlib demands
+              uint32_t lim = 0, off = 0, maxl = 0; int32_t left = 1; bool over = false;
+              uint64_t next8 = 0;
+              PC[0] = 0u | (1u << 8);
+#pragma unroll
+              for (int l = 1; l <= 7; l++) {
+                const uint32_t c = (uint32_t)(cnt8 >> (8 * l)) & 0xFFu;
+                next8 |= (uint64_t)off << (8 * l);
+                lim += c << (15 - l); off += c;
+                left = (left << 1) - (int32_t)c;
+                if (left < 0) over = true;
+                if (c) maxl = l;
+                PC[l] = (lim << 16) | ((uint32_t)(l + 1) << 8) | off;
+              }
+              if (over || (maxl != 0 && left > 0)) bad = true;
+              if (!bad)
+                for (uint32_t s = 0; s < 19; s++) {
+                  const uint32_t l = (uint32_t)(cl57 >> (3 * s)) & 7u;
+                  if (l) { const uint32_t o = (uint32_t)(next8 >> (8 * l)) & 0xFFu; next8 += 1ull << (8 * l); LB(W_DSYM * 4 + o) = (uint8_t)s; }
+                }
+            }
+            // -- code lengths of the two alphabets: nibbles at W_LENS, counts per length by LDS adds --
+#pragma unroll
+            for (int w = 0; w < 24; w++) my[(W_CL + w) * 64] = 0;
+            const uint32_t tot = nlit + ndist;
+            uint32_t i = 0, prev = 0, nw = 0;
+            while (i < tot && !bad) {
+              uint32_t rep = 1, val;
+              if (fixed) val = i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : i < 288 ? 8u : 5u;
+              else {
+                if (n < 24) HREFILL();
+                const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
+                uint32_t sel; IFL_SCAN(X, PC, 7, sel);
+                const uint32_t cl = (sel >> 8) & 0xFFu;
+                if (cl > 7) { bad = true; break; }
+                const uint32_t s = LB(W_DSYM * 4 + (sel & 0xFFu) + ((X - (sel >> 16)) >> (15 - cl)));
+                acc >>= cl; n -= cl;
+                val = s;
+                if (s == 16) { if (i == 0) { bad = true; break; } rep = 3 + ((uint32_t)acc & 3u); acc >>= 2; n -= 2; val = prev; }
+                else if (s == 17) { rep = 3 + ((uint32_t)acc & 7u); acc >>= 3; n -= 3; val = 0; }
+                else if (s == 18) { rep = 11 + ((uint32_t)acc & 127u); acc >>= 7; n -= 7; val = 0; }
+                if (budget-- == 0) { bad = true; break; }
+              }
+              if (i + rep > tot) { bad = true; break; }
+              for (uint32_t r = 0; r < rep; r++, i++) {
+                nw |= val << (4 * (i & 7u));
+                if ((i & 7u) == 7u) { my[(W_LENS + (i >> 3)) * 64] = nw; nw = 0; }
+                if (val) {
+                  const uint32_t inc = 1u << (16 * (val & 1u));
+                  if (i < nlit) { atomicAdd(&my[(W_CL + (val >> 1)) * 64], inc); if (i < 256) atomicAdd(&my[(W_NLO + (val >> 1)) * 64], inc); }
+                  else atomicAdd(&my[(W_CD + (val >> 1)) * 64], inc);
+                }
+              }
+              prev = val;
+            }
+            if (!bad) {
+              if (i & 7u) my[(W_LENS + (i >> 3)) * 64] = nw;
+              if (((my[(W_LENS + 32) * 64]) & 0xFu) == 0) bad = true;   // lens[256] == 0: no end-of-block code
+            }
+            if (!bad) {
+              // -- literal/length decode words --
+              uint32_t lim = 0, off = 0, maxl = 0; int32_t left = 1; bool over = false;
+              uint32_t cw[8], nl[8], nx[8];
+#pragma unroll
+              for (int w = 0; w < 8; w++) { cw[w] = my[(W_CL + w) * 64]; nl[w] = my[(W_NLO + w) * 64]; nx[w] = 0; }
+              P[0] = 0; Q[0] = (1u << 9) | ((nl[0] >> 16) & 0xFFFFu);
+#pragma unroll
+              for (int l = 1; l <= 15; l++) {
+                const uint32_t c = (cw[l >> 1] >> (16 * (l & 1))) & 0xFFFFu;
+                nx[l >> 1] |= off << (16 * (l & 1));
+                lim += c << (15 - l); off += c;
+                left = (left << 1) - (int32_t)c;
+                if (left < 0) over = true;
+                if (c) maxl = l;
+                const uint32_t nlo_next = l < 15 ? (nl[(l + 1) >> 1] >> (16 * ((l + 1) & 1))) & 0xFFFFu : 0u;
+                P[l] = (lim << 16) | (l < 15 ? off : 0u);
+                Q[l] = ((uint32_t)(l + 1) << 9) | (l < 15 ? off + nlo_next : 0u);
+              }
+              if (over || (left > 0 && maxl != 1)) bad = true;
+#pragma unroll
+              for (int w = 0; w < 8; w++) my[(W_CL + w) * 64] = nx[w];
+              // -- distance decode words --
+              lim = 0; off = 0; maxl = 0; left = 1; over = false;
+#pragma unroll
+              for (int w = 0; w < 8; w++) { cw[w] = my[(W_CD + w) * 64]; nx[w] = 0; }
+              PD[0] = 1u << 8;
+#pragma unroll
+              for (int l = 1; l <= 15; l++) {
+                const uint32_t c = (cw[l >> 1] >> (16 * (l & 1))) & 0xFFFFu;
+                nx[l >> 1] |= off << (16 * (l & 1));
+                lim += c << (15 - l); off += c;
+                left = (left << 1) - (int32_t)c;
+                if (left < 0) over = true;
+                if (c) maxl = l;
+                PD[l] = (lim << 16) | ((uint32_t)(l + 1) << 8) | (l < 15 ? off : 0u);
+              }
+              if (over || (maxl != 0 && left > 0 && maxl != 1)) bad = true;
+#pragma unroll
+              for (int w = 0; w < 8; w++) my[(W_CD + w) * 64] = nx[w];
+            }
+            if (!bad) {
+              // -- symbols sorted by (length, symbol): running offset per length --
+              for (uint32_t s = 0; s < tot; s++) {
+                const uint32_t v = (my[(W_LENS + (s >> 3)) * 64] >> (4 * (s & 7u))) & 0xFu;
+                if (!v) continue;
+                const uint32_t sh = 16 * (v & 1u);
+                if (s < nlit) { const uint32_t o = (atomicAdd(&my[(W_CL + (v >> 1)) * 64], 1u << sh) >> sh) & 0xFFFFu; LB(W_LSYM * 4 + o) = (uint8_t)s; }
+                else { const uint32_t o = (atomicAdd(&my[(W_CD + (v >> 1)) * 64], 1u << sh) >> sh) & 0xFFFFu; LB(W_DSYM * 4 + o) = (uint8_t)(s - nlit); }
+              }
+              HREFILL();
+              wnext = load8_at(a.streams, p, a.streams_bytes); wsh = 0;
+            }
+          }
+          if (bad) { st = ST_FIN; rem = 0; pn = 0; }
+          else st = ST_DEC;
+        }
+      }
+    }
+    LK_LAP(3);
+    if (__ballot(st != ST_DONE) == 0) break;
+    // ---- 3. streams waiting for their base chunk -------------------------------------------------------------------
+    if ((trip & 7u) == 0 && __ballot(st == ST_DEC && blocked)) {   // a poll waits for a load: not in every trip
+      bool woke = false;
+      if (st == ST_DEC && blocked) {
+        const uint32_t f = __hip_atomic_load(&a.done[bidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == 1u) {
+          const uint64_t b0 = a.raw_off[bidx], b1 = a.raw_off[bidx + 1];
+          uint64_t dl = b1 - b0;
+          dictp = a.raw_out + b0;
+          if (dl > 32768) { dictp += dl - 32768; dl = 32768; }
+          Dl = (uint32_t)dl; blocked = false; woke = true;
+        } else if (f == 2u) { bad = true; }
+        else if (++polls >= POLL_MAX) { bad = true; atomicOr(a.status, 2u); }
+        if (bad) { blocked = false; st = ST_FIN; rem = 0; pn = 0; }
+      }
+      if (__ballot(woke)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      else if (m_run == 0 && n_wait == 0) __builtin_amdgcn_s_sleep(32);
+    }
+    LK_LAP(4);
+    // ---- 4. one token ----------------------------------------------------------------------------------------------
+#ifdef HMSE_DIAG
+    cyc[7] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DEC && !blocked && rem == 0 && !eob));
+#endif
+    if (st == ST_DEC && !blocked && rem == 0) {
+      if (eob) {
+        if (pn == 0) {
+          if (!last) st = ST_WAIT;
+          else { if (pos != L || p - (n >> 3) != end) bad = true; st = ST_FIN; }
+        }
+      } else if (budget-- == 0) { bad = true; st = ST_FIN; pn = 0; }
+      else {
+        const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;   // the window was refilled in step 5
+        uint32_t sel, selq;
+        {
+          const uint32_t xk = (X << 16) | 0xFFFFu;
+          sel = P[0]; selq = Q[0];
+#pragma unroll
+          for (int j = 1; j <= 15; j++) { const bool ge = xk >= P[j]; sel = ge ? P[j] : sel; selq = ge ? Q[j] : selq; }
+        }
+        const uint32_t l1 = selq >> 9;
+        bool err = l1 > 15;
+        const uint32_t l1c = err ? 15u : l1;
+        const uint32_t idx = ((sel & 0xFFFFu) + ((X - (sel >> 16)) >> (15 - l1c))) & 0x1FFu;
+        const uint32_t sym = (uint32_t)LB(W_LSYM * 4 + (idx < 288 ? idx : 0)) | (idx >= (selq & 0x1FFu) ? 256u : 0u);
+        acc >>= l1c; n -= l1c;
+        if (err) {
+        } else if (sym < 256) {
+          if (pos >= L) err = true; else { lit = sym | 0x100u; pos++; }                // stored in step 5, at pos - 1
+        } else if (sym == 256) eob = true;
+        else if (sym > 285) err = true;
+        else {
+          // length and distance (RFC 1951 §3.2.5)
+          const uint32_t lc = sym - 257;
+          uint32_t len;
+          if (lc < 8) len = 3 + lc;
+          else if (lc == 28) len = 258;
+          else { const uint32_t e = (lc - 4) >> 2; len = 3 + ((4 + (lc & 3)) << e) + ((uint32_t)acc & ((1u << e) - 1u)); acc >>= e; n -= e; }
+          const uint32_t X2 = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
+          uint32_t seld; IFL_SCAN(X2, PD, 15, seld);
+          const uint32_t l2 = (seld >> 8) & 0xFFu;
+          if (l2 > 15) err = true;
+          else {
+            const uint32_t ds = LB(W_DSYM * 4 + (((seld & 0xFFu) + ((X2 - (seld >> 16)) >> (15 - l2))) & 31u));
+            acc >>= l2; n -= l2;
+            if (ds > 29) err = true;
+            else {
+              uint32_t dist;
+              if (ds < 4) dist = 1 + ds;
+              else { const uint32_t e = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << e) + ((uint32_t)acc & ((1u << e) - 1u)); acc >>= e; n -= e; }
+              if (pos + len > L || dist > pos + Dl) err = true;
+              else { stored = false; rem = len; cq = pos; D = dist; span = dist; pos += len; }
+            }
+          }
+        }
+        if (err) { bad = true; st = ST_FIN; rem = 0; pn = 0; }
+      }
+    }
+    LK_LAP(5);
+    // ---- 5. every memory operation of the trip, in one cluster: what it waits for was issued a whole trip ago ----------
+    // (gfx9 counts loads and stores in one counter, so a wait for a load is a wait for every store before it too: a load
+    // consumed in the middle of the trip would expose a full store round trip)
+    // Loads here are single predicated instructions whose results are first touched one trip later: an address that would
+    // run over the end of its buffer is pulled back and the value shifted when it is used (no branch around the load: a
+    // merge of a loaded and a computed value would make the compiler wait for the load on the spot).
+    // Order inside the cluster: first everything that CONSUMES last trip's loads (the one wait), then the stores, then
+    // the new loads — a wait placed after a new load would wait for that load too.
+    // The empty asm reads the three loaded values at one unconditional point: the compiler puts its single wait there and
+    // treats them as plain registers afterwards (left alone it waits again in front of each conditional use — behind the
+    // first store of the cluster, i.e. for that store's acknowledgement).
+    asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(wnext));
+    const bool fill = st == ST_DEC && !blocked && !eob;
+    if (fill) {
+      acc |= (wsh >= 64 ? 0ull : wnext >> wsh) << n;
+      const uint32_t adv = (63u - n) >> 3; p += adv; n += adv * 8u;
+    }
+#ifdef HMSE_DIAG
+    if (a.dflags & 1u) lit = 0;
+    if (a.dflags & 2u) pn = 0;
+#endif
+    if (lit) { outp[pos - 1] = (uint8_t)lit; lit = 0; }
+    if (pn) {
+      if (pback) {   // the load was pulled back from the end of the buffer: drop the bytes in front
+        const uint32_t t = pback * 8;
+        if (t >= 64) { pc0 = pc1 >> (t - 64); pc1 = 0; }
+        else { pc0 = (pc0 >> t) | (pc1 << (64 - t)); pc1 >>= t; }
+        pback = 0;
+      }
+      uint8_t* const d = outp + pdst;
+      if (pn >= 8) {
+        __builtin_memcpy(d, &pc0, 8);
+        if (pn > 8) {
+          const uint32_t t = (pn - 8) * 8;
+          const uint64_t v = t == 64 ? pc1 : (pc0 >> t) | (pc1 << (64 - t));
+          __builtin_memcpy(d + pn - 8, &v, 8);
+        }
+      } else if (pn >= 4) {
+        const uint32_t v0 = (uint32_t)pc0;
+        __builtin_memcpy(d, &v0, 4);
+        if (pn > 4) { const uint32_t v1 = (uint32_t)(pc0 >> (8 * (pn - 4))); __builtin_memcpy(d + pn - 4, &v1, 4); }
+      } else {
+        d[0] = (uint8_t)pc0;
+        if (pn >= 2) d[1] = (uint8_t)(pc0 >> 8);
+        if (pn == 3) d[2] = (uint8_t)(pc0 >> 16);
+      }
+      pn = 0;
+    }
+    if (fill) {
+      const uint64_t q = p + 8 <= a.streams_bytes ? p : a.streams_bytes - 8;      // the host side guarantees >= 8 bytes
+      const uint64_t back = p - q;
+      wsh = back >= 8 ? 64u : (uint32_t)back * 8u;
+      __builtin_memcpy(&wnext, a.streams + q, 8);
+    }
+    if (rem) {
+      uint32_t nb = rem < 16 ? rem : 16;
+      const uint8_t* s; const uint8_t* lim;
+      if (stored) { s = a.streams + sp; lim = a.streams + a.streams_bytes; }
+      else {
+        nb = nb < D ? nb : D;
+        const int32_t sv = (int32_t)cq - (int32_t)D;                  // < 0: inside the dictionary
+        if (sv < 0) { const uint32_t room = (uint32_t)(-sv); nb = nb < room ? nb : room; s = dictp + (int64_t)Dl + sv; }
+        else s = outp + sv;
+        lim = a.raw_out + a.raw_cap;
+      }
+      pback = s + 16 <= lim ? 0u : (uint32_t)(s + 16 - lim);         // <= 15: s + nb <= lim (buffers hold >= 16 bytes)
+#ifdef HMSE_DIAG
+      if (!(a.dflags & 4u))
+#endif
+      { __builtin_memcpy(&pc0, s - pback, 8); __builtin_memcpy(&pc1, s - pback + 8, 8); }
+      pdst = cq; pn = nb; cq += nb; rem -= nb;
+      if (stored) sp += nb;
+      else { span += nb; if (D < 16 && 2 * D <= span) D *= 2; }
+    }
+    LK_LAP(6);
+  }
+#ifdef HMSE_DIAG
+  if (a.trace && lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)a.trace + i, (unsigned long long)cyc[i]);
+#endif
+#undef LB
+#undef HREFILL
+#undef HTAKE
+}
+
+}  // namespace ifl
+
+namespace ifl {
+
 // chunk i of the original data = raw bytes of the stored chunk it points to (README.md:1635-1669)
 __global__ __launch_bounds__(256) void assemble_kernel(const uint64_t* __restrict__ cuts, uint64_t n_chunks,
                                                         const uint64_t* __restrict__ slot_of_chunk, uint64_t n_slots,
@@ -356,6 +834,15 @@ extern "C" void hmsedbg_inflate_trace(void* p) { g_ifl_trace = (uint32_t*)p; }
 static uint32_t* const g_ifl_trace = nullptr;
 #endif
 
+// 0 = choose by stream count, 1 = one stream per wavefront, 2 = one stream per lane
+static int g_ifl_mode = 0;
+constexpr uint64_t HMSE_INFLATE_WIDE_MIN = 32768;
+extern "C" int hmse_l1_inflate_mode(int mode) {
+  if (mode < 0 || mode > 2) return HMSE_EINVAL;
+  g_ifl_mode = mode;
+  return HMSE_OK;
+}
+
 size_t hmse_l1_inflate_workspace_bytes_impl(uint64_t n_sel) { return 256 + hmse_align_up((size_t)n_sel * 4, 256); }
 
 extern "C" int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, const uint64_t* stream_off, const uint32_t* stream_len,
@@ -374,11 +861,24 @@ extern "C" int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, c
   a.streams = streams; a.streams_bytes = streams_bytes; a.stream_off = stream_off; a.stream_len = stream_len;
   a.kind = kind; a.base = base; a.n_sel = (uint32_t)n_sel;
   a.raw_off = raw_off; a.raw_out = raw_out; a.raw_cap = raw_cap; a.status = status; a.ok = ok; a.trace = g_ifl_trace;
+  a.dflags = 0;
+#ifdef HMSE_DIAG
+  if (const char* e = getenv("HMSE_IFL_DFLAGS")) a.dflags = (uint32_t)atoi(e);
+#endif
   a.counter = (uint32_t*)ws; a.done = (uint32_t*)((uint8_t*)ws + 256);
-  uint64_t blocks = (n_sel + NT / 64 - 1) / (NT / 64);
-  if (blocks > 256 * 8) blocks = 256 * 8;  // persistent wavefronts; a waiting wavefront's base was pulled earlier, so it is running or done
+  // few streams: one per wavefront (latency of a call = one stream's decode); many: one per lane (four times the
+  // throughput once the chip's 65 536 lanes have a stream each, but a call takes as long as ~a lane's streams in sequence)
+  const bool wide = (g_ifl_mode == 2 || (g_ifl_mode == 0 && n_sel >= HMSE_INFLATE_WIDE_MIN)) && streams_bytes >= 8 && raw_cap >= 16;
   PROF_BEGIN(HMSE_STAGE_L1_INFLATE, stream);
-  l1_inflate_kernel<<<dim3((uint32_t)blocks), dim3(NT), 0, stream>>>(a);
+  if (wide) {
+    uint64_t blocks = (n_sel + 63) / 64;
+    if (blocks > 256 * 4) blocks = 256 * 4;  // persistent; 36 KiB of LDS each: four per CU
+    l1_inflate_lanes_kernel<<<dim3((uint32_t)blocks), dim3(64), 0, stream>>>(a);
+  } else {
+    uint64_t blocks = (n_sel + NT / 64 - 1) / (NT / 64);
+    if (blocks > 256 * 8) blocks = 256 * 8;  // persistent wavefronts; a waiting wavefront's base was pulled earlier, so it is running or done
+    l1_inflate_kernel<<<dim3((uint32_t)blocks), dim3(NT), 0, stream>>>(a);
+  }
   PROF_END(HMSE_STAGE_L1_INFLATE, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;

@@ -230,6 +230,11 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     return out[:total], out_off, kind
 
 
+def l1_inflate_mode(mode: int) -> None:
+    """0: pick the decoder by stream count (default); 1: one stream per wavefront; 2: one stream per lane (include/hmse.h)."""
+    _check(_lib.hip_lib().hmse_l1_inflate_mode(int(mode)), "hmse_l1_inflate_mode")
+
+
 def l1_inflate(streams: torch.Tensor, stream_off: torch.Tensor, kind: torch.Tensor, base: torch.Tensor | None,
                raw_len: torch.Tensor, stream_len: torch.Tensor | None = None, check: bool = True):
     """Raw-DEFLATE decode of stored chunks; DELTA chunks use their base chunk's raw bytes as dictionary.

@@ -19,6 +19,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["wave-per-stream", "lane-per-stream"])
+def decoder(request, dev):
+    """Every test here runs under both decoders of hmse_l1_inflate (include/hmse.h hmse_l1_inflate_mode)."""
+    from hmse_amd import ops
+    ops.l1_inflate_mode(request.param)
+    yield request.param
+    ops.l1_inflate_mode(0)
+
+
 def to_dev(a, dev):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
