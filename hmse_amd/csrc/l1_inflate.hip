@@ -401,12 +401,14 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
   bool pass2 = false;
   bool need_pull = true, bad = false, last = false, eob = false, blocked = false, stored = false;
   uint32_t k = 0, L = 0, pos = 0, Dl = 0, budget = 0, polls = 0, n = 0;
-  uint64_t bidx = 0, acc = 0, p = 0, end = 0, wnext = 0, sp = 0;
+  uint64_t bidx = 0, acc = 0, p = 0, end = 0, sp = 0;
   uint8_t* outp = a.raw_out;
   const uint8_t* dictp = a.raw_out;
   uint32_t rem = 0, cq = 0, D = 1, span = 0;                          // match / stored-block copy in progress
-  uint32_t pn = 0, pdst = 0; uint64_t pc0 = 0, pc1 = 0;               // bytes loaded last trip, stored this trip
-  uint32_t wsh = 0, pback = 0;                                        // fix-ups of loads pulled back from a buffer's end
+  uint32_t pn = 0; uint64_t pc0 = 0, pc1 = 0;                         // match piece loaded last trip, appended this trip
+  uint32_t pback = 0;                                                 // fix-up of a load pulled back from a buffer's end
+  uint64_t w0 = 0, w1 = 0; uint32_t wo = 0;                           // 16 stream bytes; byte p of the stream at offset wo
+  uint64_t ob0 = 0, ob1 = 0; uint32_t oc = 0, opos = 0; bool force = false;   // output bytes [opos, opos + oc) not stored yet
   uint32_t lit = 0;                                                   // 0x100 | literal decoded this trip
 
 #ifdef HMSE_DIAG
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
             const uint64_t s1 = a.stream_len ? s0 + a.stream_len[k] : a.stream_off[k + 1];
             if (s1 < s0 || s1 > a.streams_bytes) bad = true;
             p = s0; end = bad ? s0 : s1; acc = 0; n = 0; pos = 0; last = false; eob = false;
-            rem = 0; pn = 0;
+            rem = 0; pn = 0; oc = 0; opos = 0; force = false;
             const uint64_t bits = 8ull * (end - s0) + 64;
             budget = bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)bits;
           }
@@ -625,10 +627,10 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
                 else { const uint32_t o = (atomicAdd(&my[(W_CD + (v >> 1)) * 64], 1u << sh) >> sh) & 0xFFFFu; LB(W_DSYM * 4 + o) = (uint8_t)(s - nlit); }
               }
               HREFILL();
-              wnext = load8_at(a.streams, p, a.streams_bytes); wsh = 0;
+              w0 = load8_at(a.streams, p, a.streams_bytes); w1 = load8_at(a.streams, p + 8, a.streams_bytes); wo = 0;
             }
           }
-          if (bad) { st = ST_FIN; rem = 0; pn = 0; }
+          if (bad) { st = ST_FIN; rem = 0; pn = 0; oc = 0; }
           else st = ST_DEC;
         }
       }
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
           Dl = (uint32_t)dl; blocked = false; woke = true;
         } else if (f == 2u) { bad = true; }
         else if (++polls >= POLL_MAX) { bad = true; atomicOr(a.status, 2u); }
-        if (bad) { blocked = false; st = ST_FIN; rem = 0; pn = 0; }
+        if (bad) { blocked = false; st = ST_FIN; rem = 0; pn = 0; oc = 0; }
       }
       if (__ballot(woke)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       else if (m_run == 0 && n_wait == 0) __builtin_amdgcn_s_sleep(32);
@@ -661,10 +663,11 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
     if (st == ST_DEC && !blocked && rem == 0) {
       if (eob) {
         if (pn == 0) {
-          if (!last) st = ST_WAIT;
+          if (!last) st = ST_WAIT;                                      // the output buffer carries over into the next block
+          else if (oc != 0) force = true;                               // flushed in this trip's step 5
           else { if (pos != L || p - (n >> 3) != end) bad = true; st = ST_FIN; }
         }
-      } else if (budget-- == 0) { bad = true; st = ST_FIN; pn = 0; }
+      } else if (budget-- == 0) { bad = true; st = ST_FIN; pn = 0; oc = 0; }
       else {
         const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;   // the window was refilled in step 5
         uint32_t sel, selq;
@@ -709,83 +712,109 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
             }
           }
         }
-        if (err) { bad = true; st = ST_FIN; rem = 0; pn = 0; }
+        if (err) { bad = true; st = ST_FIN; rem = 0; pn = 0; oc = 0; }
       }
     }
     LK_LAP(5);
     // ---- 5. every memory operation of the trip, in one cluster: what it waits for was issued a whole trip ago ----------
-    // (gfx9 counts loads and stores in one counter, so a wait for a load is a wait for every store before it too: a load
-    // consumed in the middle of the trip would expose a full store round trip)
-    // Loads here are single predicated instructions whose results are first touched one trip later: an address that would
-    // run over the end of its buffer is pulled back and the value shifted when it is used (no branch around the load: a
-    // merge of a loaded and a computed value would make the compiler wait for the load on the spot).
-    // Order inside the cluster: first everything that CONSUMES last trip's loads (the one wait), then the stores, then
-    // the new loads — a wait placed after a new load would wait for that load too.
-    // The empty asm reads the three loaded values at one unconditional point: the compiler puts its single wait there and
-    // treats them as plain registers afterwards (left alone it waits again in front of each conditional use — behind the
-    // first store of the cluster, i.e. for that store's acknowledgement).
-    asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(wnext));
+    // What this kernel pays for is the NUMBER of lane-requests: every lane addresses its own cache line, and such an
+    // instruction costs the CU ~8 cycles per active lane whatever its width (tools/ubench/gmem_divergent.hip: byte store
+    // 517, unaligned dwordx4 store 516, dwordx4 load 330..470 cycles per instruction).  So:
+    //   * output goes through a 16-byte register buffer per lane (literals and match pieces appended in stream order) and
+    //     leaves as ONE 16-byte store when the next piece does not fit — the bytes behind the valid ones are garbage that
+    //     lands on positions this lane writes later anyway (never past the chunk's end: there the store is exact);
+    //   * the stream is read 16 bytes at a time into a register window, reloaded only when fewer than 8 bytes are left in it;
+    //   * a match piece is one 16-byte load (15 bytes used), issued a trip before it is appended.
+    // gfx9 counts loads and stores in ONE counter, so a wait for a load is a wait for every store before it too: all
+    // consumers of last trip's loads sit at the top of the cluster (the empty asm gives the compiler one unconditional
+    // place for its wait; left alone it waits again in front of every conditional use, i.e. behind this trip's stores),
+    // then come the stores, then the new loads.  A load whose address would run over the end of its buffer is pulled back
+    // and its value shifted when used (a branch around a load merges a loaded with a computed value, and the compiler
+    // waits for the load on the spot).
+    asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(w0), "+v"(w1));
     const bool fill = st == ST_DEC && !blocked && !eob;
     if (fill) {
-      acc |= (wsh >= 64 ? 0ull : wnext >> wsh) << n;
-      const uint32_t adv = (63u - n) >> 3; p += adv; n += adv * 8u;
+      const uint32_t sh = wo * 8u;                                     // stream byte p sits at byte wo of the window
+      const uint64_t x = sh < 64 ? w0 : w1, y = sh < 64 ? w1 : 0ull;
+      const uint32_t s6 = sh & 63u;
+      uint64_t val = s6 ? (x >> s6) | (y << (64u - s6)) : x;
+      if (sh >= 128) val = 0;
+      acc |= val << n;
+      const uint32_t adv = (63u - n) >> 3; p += adv; n += adv * 8u; wo += adv;
     }
 #ifdef HMSE_DIAG
     if (a.dflags & 1u) lit = 0;
     if (a.dflags & 2u) pn = 0;
 #endif
-    if (lit) { outp[pos - 1] = (uint8_t)lit; lit = 0; }
-    if (pn) {
-      if (pback) {   // the load was pulled back from the end of the buffer: drop the bytes in front
-        const uint32_t t = pback * 8;
-        if (t >= 64) { pc0 = pc1 >> (t - 64); pc1 = 0; }
-        else { pc0 = (pc0 >> t) | (pc1 << (64 - t)); pc1 >>= t; }
-        pback = 0;
-      }
-      uint8_t* const d = outp + pdst;
-      if (pn >= 8) {
-        __builtin_memcpy(d, &pc0, 8);
-        if (pn > 8) {
-          const uint32_t t = (pn - 8) * 8;
-          const uint64_t v = t == 64 ? pc1 : (pc0 >> t) | (pc1 << (64 - t));
-          __builtin_memcpy(d + pn - 8, &v, 8);
-        }
-      } else if (pn >= 4) {
-        const uint32_t v0 = (uint32_t)pc0;
-        __builtin_memcpy(d, &v0, 4);
-        if (pn > 4) { const uint32_t v1 = (uint32_t)(pc0 >> (8 * (pn - 4))); __builtin_memcpy(d + pn - 4, &v1, 4); }
-      } else {
-        d[0] = (uint8_t)pc0;
-        if (pn >= 2) d[1] = (uint8_t)(pc0 >> 8);
-        if (pn == 3) d[2] = (uint8_t)(pc0 >> 16);
-      }
-      pn = 0;
+    if (pn && pback) {   // the load was pulled back from the end of the buffer: drop the bytes in front
+      const uint32_t t = pback * 8;
+      if (t >= 64) { pc0 = pc1 >> (t - 64); pc1 = 0; }
+      else { pc0 = (pc0 >> t) | (pc1 << (64 - t)); pc1 >>= t; }
+      pback = 0;
     }
-    if (fill) {
-      const uint64_t q = p + 8 <= a.streams_bytes ? p : a.streams_bytes - 8;      // the host side guarantees >= 8 bytes
+    const uint32_t m_in = pn + (lit ? 1u : 0u);
+    if (oc != 0 && (force || oc + m_in > 16)) {
+      uint8_t* const d = outp + opos;
+      if (opos + 16 <= L) { __builtin_memcpy(d, &ob0, 8); __builtin_memcpy(d + 8, &ob1, 8); }
+      else if (oc >= 8) {                                              // the chunk's last bytes: exactly oc of them
+        __builtin_memcpy(d, &ob0, 8);
+        if (oc > 8) {
+          const uint32_t t = (oc - 8) * 8;
+          const uint64_t v = t == 64 ? ob1 : (ob0 >> t) | (ob1 << (64 - t));
+          __builtin_memcpy(d + oc - 8, &v, 8);
+        }
+      } else if (oc >= 4) {
+        const uint32_t v0 = (uint32_t)ob0;
+        __builtin_memcpy(d, &v0, 4);
+        if (oc > 4) { const uint32_t v1 = (uint32_t)(ob0 >> (8 * (oc - 4))); __builtin_memcpy(d + oc - 4, &v1, 4); }
+      } else {
+        d[0] = (uint8_t)ob0;
+        if (oc >= 2) d[1] = (uint8_t)(ob0 >> 8);
+        if (oc == 3) d[2] = (uint8_t)(ob0 >> 16);
+      }
+      opos += oc; oc = 0; force = false;
+    }
+    // append: ob = (ob & bytes below oc) | x << 8*oc; whatever x carries above its valid bytes lands above the new oc
+#define OB_APPEND(x0, x1, cnt) do {                                                                          \
+      const uint32_t t_ = oc * 8u;                                                                           \
+      if (t_ < 64) {                                                                                         \
+        ob1 = ((x1) << t_) | (t_ ? (x0) >> (64u - t_) : 0ull);                                               \
+        ob0 = (ob0 & ((1ull << t_) - 1ull)) | ((x0) << t_);                                                  \
+      } else { const uint32_t u_ = t_ - 64u; ob1 = (ob1 & ((1ull << u_) - 1ull)) | ((x0) << u_); }           \
+      oc += (cnt);                                                                                           \
+    } while (0)
+    if (pn) { OB_APPEND(pc0, pc1, pn); pn = 0; }
+    if (lit) { const uint64_t lb = lit & 0xFFu; OB_APPEND(lb, 0ull, 1u); lit = 0; }
+#undef OB_APPEND
+    if (fill && wo > 8) {                                               // fewer than 8 bytes left in the window
+      const uint64_t q = p + 16 <= a.streams_bytes ? p : a.streams_bytes - 16;   // the host side guarantees >= 16 bytes
       const uint64_t back = p - q;
-      wsh = back >= 8 ? 64u : (uint32_t)back * 8u;
-      __builtin_memcpy(&wnext, a.streams + q, 8);
+      wo = back > 31 ? 31u : (uint32_t)back;
+      __builtin_memcpy(&w0, a.streams + q, 8); __builtin_memcpy(&w1, a.streams + q + 8, 8);
     }
     if (rem) {
-      uint32_t nb = rem < 16 ? rem : 16;
+      uint32_t nb = rem < 15 ? rem : 15;
       const uint8_t* s; const uint8_t* lim;
+      bool clash = false;
       if (stored) { s = a.streams + sp; lim = a.streams + a.streams_bytes; }
       else {
         nb = nb < D ? nb : D;
         const int32_t sv = (int32_t)cq - (int32_t)D;                  // < 0: inside the dictionary
         if (sv < 0) { const uint32_t room = (uint32_t)(-sv); nb = nb < room ? nb : room; s = dictp + (int64_t)Dl + sv; }
-        else s = outp + sv;
+        else { s = outp + sv; clash = oc != 0 && (uint32_t)sv + nb > opos; }   // source bytes still in the register buffer
         lim = a.raw_out + a.raw_cap;
       }
-      pback = s + 16 <= lim ? 0u : (uint32_t)(s + 16 - lim);         // <= 15: s + nb <= lim (buffers hold >= 16 bytes)
+      if (clash) force = true;                                          // flushed next trip, loaded the trip after
+      else {
+        pback = s + 16 <= lim ? 0u : (uint32_t)(s + 16 - lim);         // <= 15: s + nb <= lim (buffers hold >= 16 bytes)
 #ifdef HMSE_DIAG
-      if (!(a.dflags & 4u))
+        if (!(a.dflags & 4u))
 #endif
-      { __builtin_memcpy(&pc0, s - pback, 8); __builtin_memcpy(&pc1, s - pback + 8, 8); }
-      pdst = cq; pn = nb; cq += nb; rem -= nb;
-      if (stored) sp += nb;
-      else { span += nb; if (D < 16 && 2 * D <= span) D *= 2; }
+        { __builtin_memcpy(&pc0, s - pback, 8); __builtin_memcpy(&pc1, s - pback + 8, 8); }
+        pn = nb; cq += nb; rem -= nb;
+        if (stored) sp += nb;
+        else { span += nb; if (D < 16 && 2 * D <= span) D *= 2; }
+      }
     }
     LK_LAP(6);
   }
@@ -868,7 +897,7 @@ extern "C" int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, c
   a.counter = (uint32_t*)ws; a.done = (uint32_t*)((uint8_t*)ws + 256);
   // few streams: one per wavefront (latency of a call = one stream's decode); many: one per lane (four times the
   // throughput once the chip's 65 536 lanes have a stream each, but a call takes as long as ~a lane's streams in sequence)
-  const bool wide = (g_ifl_mode == 2 || (g_ifl_mode == 0 && n_sel >= HMSE_INFLATE_WIDE_MIN)) && streams_bytes >= 8 && raw_cap >= 16;
+  const bool wide = (g_ifl_mode == 2 || (g_ifl_mode == 0 && n_sel >= HMSE_INFLATE_WIDE_MIN)) && streams_bytes >= 16 && raw_cap >= 16;
   PROF_BEGIN(HMSE_STAGE_L1_INFLATE, stream);
   if (wide) {
     uint64_t blocks = (n_sel + 63) / 64;
