@@ -355,8 +355,9 @@ __global__ __launch_bounds__(NT, 8) void l1_inflate_kernel(Args a) {
 // Every wait is bounded (symbol budget per stream, poll budget per base, bytes per copy), so every lane reaches DONE.
 namespace ifl {
 
-constexpr int LW = 144;                         // LDS words per lane
-constexpr int W_LSYM = 0, W_DSYM = 72, W_LENS = 80, W_CL = 120, W_NLO = 128, W_CD = 136;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int LW = 72;                          // LDS words per lane: the sorted literal/length symbols, one byte each
+constexpr int W_LSYM = 0;
 constexpr uint32_t ST_WAIT = 0, ST_DEC = 1, ST_FIN = 2, ST_DONE = 3;
 constexpr uint32_t HDR_MIN = 16;                // lanes that must be waiting before a header round is run
 constexpr uint32_t POLL_MAX = 1u << 21;
@@ -387,13 +388,14 @@ __device__ __forceinline__ uint64_t load8_at(const uint8_t* base, uint64_t off, 
 #define LK_LAP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
+__global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   __shared__ uint32_t lds[LW * 64];
   const uint32_t lane = threadIdx.x;
   uint32_t* const my = lds + lane;                                    // word w at my[w * 64]
   uint8_t* const myb = (uint8_t*)lds + lane * 4;                      // byte B at myb[(B >> 2) * 256 + (B & 3)]
 #define LB(B) myb[(((uint32_t)(B)) >> 2) * 256u + (((uint32_t)(B)) & 3u)]
 
+  uint64_t ds0 = 0, ds1 = 0, ds2 = 0;                                 // distance symbols sorted by (length, symbol), 5 bits each
   uint32_t P[16], Q[16], PD[16];                                      // decode words of the current block (see IFL_SCAN)
 #pragma unroll
   for (int j = 0; j < 16; j++) { P[j] = 0; Q[j] = 0; PD[j] = 0; }
@@ -504,13 +506,45 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
             uint32_t PC[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) PC[j] = 0;
+            uint64_t cs0 = 0, cs1 = 0;             // code-length symbols sorted by (length, symbol): 5 bits each, 12 per word
+            // A dynamic header is read from LDS: the next 288 stream bytes are staged in the (not yet needed) symbol area
+            // with 18 loads in flight at once — read from global memory it costs a full round trip every few symbols,
+            // ~300 of them in a row.  B0 = stream byte of LDS byte 0; lp = next LDS byte to enter the window.
+            bool staged = false; uint64_t B0 = 0; uint32_t lp = 0;
+#define LREFILL() do {                                                                                                   \
+              if (staged && lp + 8 <= 288) {                                                                               \
+                const uint32_t k_ = lp >> 2, r_ = (lp & 3u) * 8u;                                                          \
+                const uint64_t lo_ = (uint64_t)my[k_ * 64] | ((uint64_t)my[(k_ + 1) * 64] << 32);                          \
+                const uint64_t hi_ = my[(k_ + 2 < 72 ? k_ + 2 : 71) * 64];                                                 \
+                const uint64_t w_ = r_ ? (lo_ >> r_) | (hi_ << (64u - r_)) : lo_;                                          \
+                acc |= w_ << n; const uint32_t adv_ = (63u - n) >> 3; lp += adv_; n += adv_ * 8u;                          \
+              } else {                                                                                                     \
+                if (staged) { p = B0 + lp; staged = false; }                                                               \
+                HREFILL();                                                                                                 \
+              }                                                                                                            \
+            } while (0)
             if (!fixed) {
               uint32_t t5; HTAKE(5, t5); nlit = t5 + 257; HTAKE(5, t5); ndist = t5 + 1;
               uint32_t ncl; HTAKE(4, ncl); ncl += 4;
               if (nlit > 286 || ndist > 30) bad = true;
+              {
+                const uint64_t bitpos = 8ull * p - n;
+                B0 = bitpos >> 3;
+                if (!bad && B0 + 288 <= a.streams_bytes) {
+                  u32x4 sv[18];
+#pragma unroll
+                  for (int j = 0; j < 18; j++) __builtin_memcpy(&sv[j], a.streams + B0 + 16 * j, 16);
+#pragma unroll
+                  for (int j = 0; j < 18; j++) { my[(4 * j) * 64] = sv[j].x; my[(4 * j + 1) * 64] = sv[j].y; my[(4 * j + 2) * 64] = sv[j].z; my[(4 * j + 3) * 64] = sv[j].w; }
+                  staged = true; lp = 0; acc = 0; n = 0;
+                  LREFILL();
+                  const uint32_t skip = (uint32_t)bitpos & 7u; acc >>= skip; n -= skip;
+                }
+              }
               uint64_t cl57 = 0;   // code-length code lengths, 3 bits per symbol
               for (uint32_t i = 0; i < ncl; i++) {
-                uint32_t v; HTAKE(3, v);
+                if (n < 3) LREFILL();
+                const uint32_t v = (uint32_t)acc & 7u; acc >>= 3; n -= 3;
                 // order of the code-length code lengths (RFC 1951 §3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                 const uint32_t o = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? (19 - i) >> 1 : 6 + (i >> 1);
                 cl57 |= (uint64_t)v << (3 * o);
@@ -535,78 +569,92 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
               if (!bad)
                 for (uint32_t s = 0; s < 19; s++) {
                   const uint32_t l = (uint32_t)(cl57 >> (3 * s)) & 7u;
-                  if (l) { const uint32_t o = (uint32_t)(next8 >> (8 * l)) & 0xFFu; next8 += 1ull << (8 * l); LB(W_DSYM * 4 + o) = (uint8_t)s; }
+                  if (l) {
+                    const uint32_t o = (uint32_t)(next8 >> (8 * l)) & 0xFFu; next8 += 1ull << (8 * l);
+                    if (o < 12) cs0 |= (uint64_t)s << (5 * o); else cs1 |= (uint64_t)s << (5 * (o - 12));
+                  }
                 }
             }
-            // -- code lengths of the two alphabets: nibbles at W_LENS, counts per length by LDS adds --
+            // -- code lengths of the two alphabets.  They are needed twice, in order (counted per length now, placed by
+            // rank afterwards): eight 4-bit lengths per word go through a 40-register FIFO — registers cannot be indexed
+            // by a lane, but a queue only ever moves by one.  Counts per length live in packed registers as well:
+            // literal/length and literals-only counts in 16-bit fields (four lengths per 64-bit word), distance counts in
+            // 8-bit fields.  LDS holds nothing but the sorted literal/length symbols: 288 bytes per lane.
+            uint32_t LF[40];
 #pragma unroll
-            for (int w = 0; w < 24; w++) my[(W_CL + w) * 64] = 0;
+            for (int j = 0; j < 40; j++) LF[j] = 0;
+#define LF_PUSH(wd) do { _Pragma("unroll") for (int j_ = 39; j_ > 0; j_--) LF[j_] = LF[j_ - 1]; LF[0] = (wd); } while (0)
+            uint64_t lc[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0}, dc[2] = {0, 0};
             const uint32_t tot = nlit + ndist;
-            uint32_t i = 0, prev = 0, nw = 0;
+            uint32_t i = 0, prev = 0, nw = 0, npush = 0;
             while (i < tot && !bad) {
               uint32_t rep = 1, val;
               if (fixed) val = i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : i < 288 ? 8u : 5u;
               else {
-                if (n < 24) HREFILL();
+                if (n < 24) LREFILL();
                 const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
                 uint32_t sel; IFL_SCAN(X, PC, 7, sel);
                 const uint32_t cl = (sel >> 8) & 0xFFu;
                 if (cl > 7) { bad = true; break; }
-                const uint32_t s = LB(W_DSYM * 4 + (sel & 0xFFu) + ((X - (sel >> 16)) >> (15 - cl)));
+                const uint32_t ci = ((sel & 0xFFu) + ((X - (sel >> 16)) >> (15 - cl))) & 31u;
+                const uint32_t s = (uint32_t)(ci < 12 ? cs0 >> (5 * ci) : cs1 >> (5 * (ci < 24 ? ci - 12 : 0))) & 31u;
                 acc >>= cl; n -= cl;
                 val = s;
                 if (s == 16) { if (i == 0) { bad = true; break; } rep = 3 + ((uint32_t)acc & 3u); acc >>= 2; n -= 2; val = prev; }
                 else if (s == 17) { rep = 3 + ((uint32_t)acc & 7u); acc >>= 3; n -= 3; val = 0; }
                 else if (s == 18) { rep = 11 + ((uint32_t)acc & 127u); acc >>= 7; n -= 7; val = 0; }
-                if (budget-- == 0) { bad = true; break; }
+                if (s > 18 || budget-- == 0) { bad = true; break; }
               }
               if (i + rep > tot) { bad = true; break; }
               for (uint32_t r = 0; r < rep; r++, i++) {
                 nw |= val << (4 * (i & 7u));
-                if ((i & 7u) == 7u) { my[(W_LENS + (i >> 3)) * 64] = nw; nw = 0; }
+                if ((i & 7u) == 7u) { LF_PUSH(nw); nw = 0; npush++; }
                 if (val) {
-                  const uint32_t inc = 1u << (16 * (val & 1u));
-                  if (i < nlit) { atomicAdd(&my[(W_CL + (val >> 1)) * 64], inc); if (i < 256) atomicAdd(&my[(W_NLO + (val >> 1)) * 64], inc); }
-                  else atomicAdd(&my[(W_CD + (val >> 1)) * 64], inc);
+                  if (i < nlit) {
+                    const uint64_t inc = 1ull << (16 * (val & 3u));
+                    const uint32_t r4 = val >> 2;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { lc[q] += r4 == (uint32_t)q ? inc : 0ull; nl[q] += (r4 == (uint32_t)q && i < 256) ? inc : 0ull; }
+                  } else {
+                    const uint64_t inc = 1ull << (8 * (val & 7u));
+                    dc[0] += val < 8 ? inc : 0ull; dc[1] += val >= 8 ? inc : 0ull;
+                  }
                 }
               }
               prev = val;
             }
             if (!bad) {
-              if (i & 7u) my[(W_LENS + (i >> 3)) * 64] = nw;
-              if (((my[(W_LENS + 32) * 64]) & 0xFu) == 0) bad = true;   // lens[256] == 0: no end-of-block code
+              if (i & 7u) { LF_PUSH(nw); npush++; }
+              for (; npush < 40; npush++) LF_PUSH(0u);                  // word 0 of the lengths now sits in LF[39]
+              // lens[256] == 0: no end-of-block code.  Word 32 is 7 pushes above the last one.
+              if ((LF[7] & 0xFu) == 0) bad = true;
             }
+            if (staged) { p = B0 + lp; staged = false; }                 // back to the stream itself
+            uint64_t nxl[4] = {0, 0, 0, 0}, nxd[2] = {0, 0};             // running offset per length (the counts' layout)
             if (!bad) {
               // -- literal/length decode words --
               uint32_t lim = 0, off = 0, maxl = 0; int32_t left = 1; bool over = false;
-              uint32_t cw[8], nl[8], nx[8];
-#pragma unroll
-              for (int w = 0; w < 8; w++) { cw[w] = my[(W_CL + w) * 64]; nl[w] = my[(W_NLO + w) * 64]; nx[w] = 0; }
-              P[0] = 0; Q[0] = (1u << 9) | ((nl[0] >> 16) & 0xFFFFu);
+              P[0] = 0; Q[0] = (1u << 9) | ((uint32_t)(nl[0] >> 16) & 0xFFFFu);
 #pragma unroll
               for (int l = 1; l <= 15; l++) {
-                const uint32_t c = (cw[l >> 1] >> (16 * (l & 1))) & 0xFFFFu;
-                nx[l >> 1] |= off << (16 * (l & 1));
+                const uint32_t c = (uint32_t)(lc[l >> 2] >> (16 * (l & 3))) & 0xFFFFu;
+                nxl[l >> 2] |= (uint64_t)off << (16 * (l & 3));
                 lim += c << (15 - l); off += c;
                 left = (left << 1) - (int32_t)c;
                 if (left < 0) over = true;
                 if (c) maxl = l;
-                const uint32_t nlo_next = l < 15 ? (nl[(l + 1) >> 1] >> (16 * ((l + 1) & 1))) & 0xFFFFu : 0u;
+                const uint32_t nlo_next = l < 15 ? (uint32_t)(nl[(l + 1) >> 2] >> (16 * ((l + 1) & 3))) & 0xFFFFu : 0u;
                 P[l] = (lim << 16) | (l < 15 ? off : 0u);
                 Q[l] = ((uint32_t)(l + 1) << 9) | (l < 15 ? off + nlo_next : 0u);
               }
               if (over || (left > 0 && maxl != 1)) bad = true;
-#pragma unroll
-              for (int w = 0; w < 8; w++) my[(W_CL + w) * 64] = nx[w];
               // -- distance decode words --
               lim = 0; off = 0; maxl = 0; left = 1; over = false;
-#pragma unroll
-              for (int w = 0; w < 8; w++) { cw[w] = my[(W_CD + w) * 64]; nx[w] = 0; }
               PD[0] = 1u << 8;
 #pragma unroll
               for (int l = 1; l <= 15; l++) {
-                const uint32_t c = (cw[l >> 1] >> (16 * (l & 1))) & 0xFFFFu;
-                nx[l >> 1] |= off << (16 * (l & 1));
+                const uint32_t c = (uint32_t)(dc[l >> 3] >> (8 * (l & 7))) & 0xFFu;
+                nxd[l >> 3] |= (uint64_t)off << (8 * (l & 7));
                 lim += c << (15 - l); off += c;
                 left = (left << 1) - (int32_t)c;
                 if (left < 0) over = true;
@@ -614,21 +662,42 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
                 PD[l] = (lim << 16) | ((uint32_t)(l + 1) << 8) | (l < 15 ? off : 0u);
               }
               if (over || (maxl != 0 && left > 0 && maxl != 1)) bad = true;
-#pragma unroll
-              for (int w = 0; w < 8; w++) my[(W_CD + w) * 64] = nx[w];
             }
             if (!bad) {
-              // -- symbols sorted by (length, symbol): running offset per length --
-              for (uint32_t s = 0; s < tot; s++) {
-                const uint32_t v = (my[(W_LENS + (s >> 3)) * 64] >> (4 * (s & 7u))) & 0xFu;
-                if (!v) continue;
-                const uint32_t sh = 16 * (v & 1u);
-                if (s < nlit) { const uint32_t o = (atomicAdd(&my[(W_CL + (v >> 1)) * 64], 1u << sh) >> sh) & 0xFFFFu; LB(W_LSYM * 4 + o) = (uint8_t)s; }
-                else { const uint32_t o = (atomicAdd(&my[(W_CD + (v >> 1)) * 64], 1u << sh) >> sh) & 0xFFFFu; LB(W_DSYM * 4 + o) = (uint8_t)(s - nlit); }
+              // -- symbols sorted by (length, symbol): literal/length symbols into LDS, distance symbols into registers --
+              ds0 = 0; ds1 = 0; ds2 = 0;
+              const uint32_t nwords = (tot + 7) >> 3;
+              for (uint32_t w = 0; w < nwords; w++) {
+                const uint32_t word = LF[39];
+                LF_PUSH(0u);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                  const uint32_t s = w * 8 + j;
+                  const uint32_t v = (word >> (4 * j)) & 0xFu;
+                  if (!v) continue;                                       // (symbols >= tot have length 0)
+                  if (s < nlit) {
+                    const uint32_t r4 = v >> 2, sh = 16 * (v & 3u);
+                    const uint64_t cur = r4 == 0 ? nxl[0] : r4 == 1 ? nxl[1] : r4 == 2 ? nxl[2] : nxl[3];
+                    const uint32_t o = (uint32_t)(cur >> sh) & 0xFFFFu;
+                    const uint64_t inc = 1ull << sh;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) nxl[q] += r4 == (uint32_t)q ? inc : 0ull;
+                    LB(W_LSYM * 4 + (o < 288 ? o : 0)) = (uint8_t)s;
+                  } else {
+                    const uint32_t sh = 8 * (v & 7u);
+                    const uint32_t o = (uint32_t)((v < 8 ? nxd[0] : nxd[1]) >> sh) & 0xFFu;
+                    const uint64_t inc = 1ull << sh;
+                    nxd[0] += v < 8 ? inc : 0ull; nxd[1] += v >= 8 ? inc : 0ull;
+                    const uint64_t dsym = (uint64_t)(s - nlit) << (5 * (o % 12u));
+                    ds0 |= o < 12 ? dsym : 0ull; ds1 |= (o >= 12 && o < 24) ? dsym : 0ull; ds2 |= (o >= 24 && o < 36) ? dsym : 0ull;
+                  }
+                }
               }
               HREFILL();
               w0 = load8_at(a.streams, p, a.streams_bytes); w1 = load8_at(a.streams, p + 8, a.streams_bytes); wo = 0;
             }
+#undef LF_PUSH
+#undef LREFILL
           }
           if (bad) { st = ST_FIN; rem = 0; pn = 0; oc = 0; }
           else st = ST_DEC;
@@ -700,7 +769,9 @@ __global__ __launch_bounds__(64, 1) void l1_inflate_lanes_kernel(Args a) {
           const uint32_t l2 = (seld >> 8) & 0xFFu;
           if (l2 > 15) err = true;
           else {
-            const uint32_t ds = LB(W_DSYM * 4 + (((seld & 0xFFu) + ((X2 - (seld >> 16)) >> (15 - l2))) & 31u));
+            const uint32_t di = ((seld & 0xFFu) + ((X2 - (seld >> 16)) >> (15 - l2))) & 31u;
+            const uint32_t dj = di < 12 ? di : di < 24 ? di - 12 : di - 24;
+            const uint32_t ds = (uint32_t)((di < 12 ? ds0 : di < 24 ? ds1 : ds2) >> (5 * dj)) & 31u;
             acc >>= l2; n -= l2;
             if (ds > 29) err = true;
             else {
@@ -901,7 +972,7 @@ extern "C" int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, c
   PROF_BEGIN(HMSE_STAGE_L1_INFLATE, stream);
   if (wide) {
     uint64_t blocks = (n_sel + 63) / 64;
-    if (blocks > 256 * 4) blocks = 256 * 4;  // persistent; 36 KiB of LDS each: four per CU
+    if (blocks > 256 * 8) blocks = 256 * 8;  // persistent; 18 KiB of LDS each: eight per CU, two per SIMD
     l1_inflate_lanes_kernel<<<dim3((uint32_t)blocks), dim3(64), 0, stream>>>(a);
   } else {
     uint64_t blocks = (n_sel + NT / 64 - 1) / (NT / 64);

@@ -23,7 +23,7 @@ trace.zero_()
 ops.l1_inflate(res.streams, res.stream_off, res.kind, res.base, lens)
 torch.cuda.synchronize()
 t = trace.tolist()
-waves = min((res.kind.numel() + 63) // 64, 1024)
+waves = min((res.kind.numel() + 63) // 64, 2048)
 names = ["trips", "header rounds", "publish", "header", "poll", "decode", "memory cluster", "lane-trips decoding"]
 print(f"{res.kind.numel()} records, {waves} wavefronts")
 for i, nm in enumerate(names):
