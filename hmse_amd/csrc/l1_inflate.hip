@@ -359,7 +359,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LW = 72;                          // LDS words per lane: the sorted literal/length symbols, one byte each
 constexpr int W_LSYM = 0;
 constexpr uint32_t ST_WAIT = 0, ST_DEC = 1, ST_FIN = 2, ST_DONE = 3;
-constexpr uint32_t HDR_MIN = 16;                // lanes that must be waiting before a header round is run
+#ifndef HMSE_HDR_MIN
+#define HMSE_HDR_MIN 16
+#endif
+constexpr uint32_t HDR_MIN = HMSE_HDR_MIN;                // lanes that must be waiting before a header round is run
 constexpr uint32_t POLL_MAX = 1u << 21;
 
 __device__ __forceinline__ uint64_t load8_at(const uint8_t* base, uint64_t off, uint64_t total) {
@@ -401,7 +404,10 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   for (int j = 0; j < 16; j++) { P[j] = 0; Q[j] = 0; PD[j] = 0; }
   uint32_t st = ST_WAIT;
   bool pass2 = false;
-  bool need_pull = true, bad = false, last = false, eob = false, blocked = false, stored = false;
+  bool need_pull = true;
+  // lane flags as 0/1 words in VGPRs: as bools they live as lane masks in SGPRs, and every update in divergent code costs
+  // three scalar mask operations
+  uint32_t bad = 0, last = 0, eob = 0, blocked = 0, stored = 0, force = 0;
   uint32_t k = 0, L = 0, pos = 0, Dl = 0, budget = 0, polls = 0, n = 0;
   uint64_t bidx = 0, acc = 0, p = 0, end = 0, sp = 0;
   uint8_t* outp = a.raw_out;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   uint32_t pn = 0; uint64_t pc0 = 0, pc1 = 0;                         // match piece loaded last trip, appended this trip
   uint32_t pback = 0;                                                 // fix-up of a load pulled back from a buffer's end
   uint64_t w0 = 0, w1 = 0; uint32_t wo = 0;                           // 16 stream bytes; byte p of the stream at offset wo
-  uint64_t ob0 = 0, ob1 = 0; uint32_t oc = 0, opos = 0; bool force = false;   // output bytes [opos, opos + oc) not stored yet
+  uint64_t ob0 = 0, ob1 = 0; uint32_t oc = 0, opos = 0;   // output bytes [opos, opos + oc) not stored yet
   uint32_t lit = 0;                                                   // 0x100 | literal decoded this trip
 
 #ifdef HMSE_DIAG
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
             const uint64_t s1 = a.stream_len ? s0 + a.stream_len[k] : a.stream_off[k + 1];
             if (s1 < s0 || s1 > a.streams_bytes) bad = true;
             p = s0; end = bad ? s0 : s1; acc = 0; n = 0; pos = 0; last = false; eob = false;
-            rem = 0; pn = 0; oc = 0; opos = 0; force = false;
+            rem = 0; pn = 0; oc = 0; opos = 0; force = 0;
             const uint64_t bits = 8ull * (end - s0) + 64;
             budget = bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)bits;
           }
@@ -729,62 +735,66 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
 #ifdef HMSE_DIAG
     cyc[7] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DEC && !blocked && rem == 0 && !eob));
 #endif
-    if (st == ST_DEC && !blocked && rem == 0) {
-      if (eob) {
-        if (pn == 0) {
-          if (!last) st = ST_WAIT;                                      // the output buffer carries over into the next block
-          else if (oc != 0) force = true;                               // flushed in this trip's step 5
-          else { if (pos != L || p - (n >> 3) != end) bad = true; st = ST_FIN; }
-        }
-      } else if (budget-- == 0) { bad = true; st = ST_FIN; pn = 0; oc = 0; }
-      else {
-        const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;   // the window was refilled in step 5
-        uint32_t sel, selq;
-        {
-          const uint32_t xk = (X << 16) | 0xFFFFu;
-          sel = P[0]; selq = Q[0];
-#pragma unroll
-          for (int j = 1; j <= 15; j++) { const bool ge = xk >= P[j]; sel = ge ? P[j] : sel; selq = ge ? Q[j] : selq; }
-        }
-        const uint32_t l1 = selq >> 9;
-        bool err = l1 > 15;
-        const uint32_t l1c = err ? 15u : l1;
-        const uint32_t idx = ((sel & 0xFFFFu) + ((X - (sel >> 16)) >> (15 - l1c))) & 0x1FFu;
-        const uint32_t sym = (uint32_t)LB(W_LSYM * 4 + (idx < 288 ? idx : 0)) | (idx >= (selq & 0x1FFu) ? 256u : 0u);
-        acc >>= l1c; n -= l1c;
-        if (err) {
-        } else if (sym < 256) {
-          if (pos >= L) err = true; else { lit = sym | 0x100u; pos++; }                // stored in step 5, at pos - 1
-        } else if (sym == 256) eob = true;
-        else if (sym > 285) err = true;
-        else {
-          // length and distance (RFC 1951 §3.2.5)
-          const uint32_t lc = sym - 257;
-          uint32_t len;
-          if (lc < 8) len = 3 + lc;
-          else if (lc == 28) len = 258;
-          else { const uint32_t e = (lc - 4) >> 2; len = 3 + ((4 + (lc & 3)) << e) + ((uint32_t)acc & ((1u << e) - 1u)); acc >>= e; n -= e; }
-          const uint32_t X2 = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
-          uint32_t seld; IFL_SCAN(X2, PD, 15, seld);
-          const uint32_t l2 = (seld >> 8) & 0xFFu;
-          if (l2 > 15) err = true;
-          else {
-            const uint32_t di = ((seld & 0xFFu) + ((X2 - (seld >> 16)) >> (15 - l2))) & 31u;
-            const uint32_t dj = di < 12 ? di : di < 24 ? di - 12 : di - 24;
-            const uint32_t ds = (uint32_t)((di < 12 ? ds0 : di < 24 ? ds1 : ds2) >> (5 * dj)) & 31u;
-            acc >>= l2; n -= l2;
-            if (ds > 29) err = true;
-            else {
-              uint32_t dist;
-              if (ds < 4) dist = 1 + ds;
-              else { const uint32_t e = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << e) + ((uint32_t)acc & ((1u << e) - 1u)); acc >>= e; n -= e; }
-              if (pos + len > L || dist > pos + Dl) err = true;
-              else { stored = false; rem = len; cq = pos; D = dist; span = dist; pos += len; }
-            }
-          }
-        }
-        if (err) { bad = true; st = ST_FIN; rem = 0; pn = 0; oc = 0; }
+    const bool dec = st == ST_DEC && !blocked && rem == 0;
+    if (dec && eob) {                                                   // end of a block: rare, a real branch
+      if (pn == 0) {
+        if (!last) st = ST_WAIT;                                        // the output buffer carries over into the next block
+        else if (oc != 0) force = 1;                                    // flushed in this trip's step 5
+        else { if (pos != L || p - (n >> 3) != end) bad = 1; st = ST_FIN; }
       }
+    }
+    if (dec && !eob) {
+      // Straight-line code: every lane computes the literal, the end-of-block and the length/distance outcome and keeps
+      // the one its symbol selects (with 64 independent streams every path is taken in every trip anyway; as nested ifs
+      // the step was half scalar mask bookkeeping and branches).  A lane whose symbol is no length consumes 0 extra bits
+      // and a 0-bit distance code.
+      uint32_t err = budget == 0 ? 1u : 0u;
+      budget -= 1;
+      const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;   // the window was refilled in step 5
+      uint32_t sel, selq;
+      {
+        const uint32_t xk = (X << 16) | 0xFFFFu;
+        sel = P[0]; selq = Q[0];
+#pragma unroll
+        for (int j = 1; j <= 15; j++) { const bool ge = xk >= P[j]; sel = ge ? P[j] : sel; selq = ge ? Q[j] : selq; }
+      }
+      const uint32_t l1 = selq >> 9;
+      err |= l1 > 15 ? 1u : 0u;
+      const uint32_t l1c = l1 > 15 ? 15u : l1;
+      const uint32_t idx = ((sel & 0xFFFFu) + ((X - (sel >> 16)) >> (15 - l1c))) & 0x1FFu;
+      const uint32_t sym = (uint32_t)LB(W_LSYM * 4 + (idx < 288 ? idx : 0)) | (idx >= (selq & 0x1FFu) ? 256u : 0u);
+      acc >>= l1c; n -= l1c;
+      const bool is_lit = sym < 256, is_len = sym > 256;
+      err |= sym > 285 ? 1u : 0u;
+      // length and distance (RFC 1951 §3.2.5)
+      const uint32_t lcx = is_len ? (sym - 257u) & 31u : 0u;
+      const bool lshort = lcx < 8 || lcx >= 28;
+      const uint32_t e1 = lshort ? 0u : (lcx - 4) >> 2;
+      const uint32_t lb = lcx < 8 ? 3 + lcx : lcx >= 28 ? 258u : 3 + ((4 + (lcx & 3)) << e1);
+      const uint32_t len = lb + ((uint32_t)acc & ((1u << e1) - 1u));
+      acc >>= e1; n -= e1;
+      const uint32_t X2 = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
+      uint32_t seld; IFL_SCAN(X2, PD, 15, seld);
+      const uint32_t l2r = (seld >> 8) & 0xFFu;
+      const uint32_t l2c = l2r > 15 ? 15u : l2r;
+      const uint32_t di = ((seld & 0xFFu) + ((X2 - (seld >> 16)) >> (15 - l2c))) & 31u;
+      const uint32_t dj = di < 12 ? di : di < 24 ? di - 12 : di - 24;
+      const uint32_t ds = (uint32_t)((di < 12 ? ds0 : di < 24 ? ds1 : ds2) >> (5 * dj)) & 31u;
+      err |= (is_len && (l2r > 15 || ds > 29)) ? 1u : 0u;
+      const uint32_t l2 = is_len ? l2c : 0u;
+      acc >>= l2; n -= l2;
+      const uint32_t e2 = (is_len && ds >= 4) ? ((ds >> 1) - 1u) & 15u : 0u;
+      const uint32_t dist = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << e2) + ((uint32_t)acc & ((1u << e2) - 1u));
+      acc >>= e2; n -= e2;
+      err |= (is_lit && pos >= L) ? 1u : 0u;
+      err |= (is_len && (pos + len > L || dist > pos + Dl)) ? 1u : 0u;
+      if (!err) {
+        lit = is_lit ? sym | 0x100u : 0u;                                // appended to the output buffer in step 5
+        eob = sym == 256 ? 1u : 0u;
+        rem = is_len ? len : 0u;
+        cq = is_len ? pos : cq; D = is_len ? dist : D; span = is_len ? dist : span; stored = is_len ? 0u : stored;
+        pos += is_lit ? 1u : is_len ? len : 0u;
+      } else { bad = 1; st = ST_FIN; rem = 0; pn = 0; oc = 0; }
     }
     LK_LAP(5);
     // ---- 5. every memory operation of the trip, in one cluster: what it waits for was issued a whole trip ago ----------
@@ -804,14 +814,15 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
     // waits for the load on the spot).
     asm volatile("" : "+v"(pc0), "+v"(pc1), "+v"(w0), "+v"(w1));
     const bool fill = st == ST_DEC && !blocked && !eob;
-    if (fill) {
+    {
       const uint32_t sh = wo * 8u;                                     // stream byte p sits at byte wo of the window
       const uint64_t x = sh < 64 ? w0 : w1, y = sh < 64 ? w1 : 0ull;
       const uint32_t s6 = sh & 63u;
-      uint64_t val = s6 ? (x >> s6) | (y << (64u - s6)) : x;
-      if (sh >= 128) val = 0;
-      acc |= val << n;
-      const uint32_t adv = (63u - n) >> 3; p += adv; n += adv * 8u; wo += adv;
+      uint64_t val = (x >> s6) | (s6 ? y << (64u - s6) : 0ull);
+      val = sh >= 128 ? 0ull : val;
+      const uint32_t adv = fill ? (63u - n) >> 3 : 0u;
+      acc |= fill ? val << n : 0ull;
+      p += adv; n += adv * 8u; wo += adv;
     }
 #ifdef HMSE_DIAG
     if (a.dflags & 1u) lit = 0;
@@ -843,19 +854,21 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
         if (oc >= 2) d[1] = (uint8_t)(ob0 >> 8);
         if (oc == 3) d[2] = (uint8_t)(ob0 >> 16);
       }
-      opos += oc; oc = 0; force = false;
+      opos += oc; oc = 0; force = 0;
     }
-    // append: ob = (ob & bytes below oc) | x << 8*oc; whatever x carries above its valid bytes lands above the new oc
+    // append: ob = (ob & bytes below oc) | x << 8*oc; whatever x carries above its valid bytes lands above the new oc —
+    // so appending 0 bytes of anything is harmless and both appends run unconditionally
 #define OB_APPEND(x0, x1, cnt) do {                                                                          \
-      const uint32_t t_ = oc * 8u;                                                                           \
-      if (t_ < 64) {                                                                                         \
-        ob1 = ((x1) << t_) | (t_ ? (x0) >> (64u - t_) : 0ull);                                               \
-        ob0 = (ob0 & ((1ull << t_) - 1ull)) | ((x0) << t_);                                                  \
-      } else { const uint32_t u_ = t_ - 64u; ob1 = (ob1 & ((1ull << u_) - 1ull)) | ((x0) << u_); }           \
+      const uint32_t t_ = oc * 8u, u_ = t_ & 63u;                                                            \
+      const uint64_t keep_ = (1ull << u_) - 1ull, up_ = (x0) << u_;                                          \
+      const uint64_t carry_ = u_ ? (x0) >> (64u - u_) : 0ull;                                                \
+      const uint64_t n0_ = (ob0 & keep_) | up_, n1a_ = ((x1) << u_) | carry_, n1b_ = (ob1 & keep_) | up_;    \
+      ob1 = t_ < 64 ? n1a_ : t_ < 128 ? n1b_ : ob1;                                                          \
+      ob0 = t_ < 64 ? n0_ : ob0;                                                                             \
       oc += (cnt);                                                                                           \
     } while (0)
-    if (pn) { OB_APPEND(pc0, pc1, pn); pn = 0; }
-    if (lit) { const uint64_t lb = lit & 0xFFu; OB_APPEND(lb, 0ull, 1u); lit = 0; }
+    OB_APPEND(pc0, pc1, pn); pn = 0;
+    { const uint64_t lb = lit & 0xFFu; OB_APPEND(lb, 0ull, (lit ? 1u : 0u)); lit = 0; }
 #undef OB_APPEND
     if (fill && wo > 8) {                                               // fewer than 8 bytes left in the window
       const uint64_t q = p + 16 <= a.streams_bytes ? p : a.streams_bytes - 16;   // the host side guarantees >= 16 bytes
@@ -875,7 +888,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
         else { s = outp + sv; clash = oc != 0 && (uint32_t)sv + nb > opos; }   // source bytes still in the register buffer
         lim = a.raw_out + a.raw_cap;
       }
-      if (clash) force = true;                                          // flushed next trip, loaded the trip after
+      if (clash) force = 1;                                             // flushed next trip, loaded the trip after
       else {
         pback = s + 16 <= lim ? 0u : (uint32_t)(s + 16 - lim);         // <= 15: s + nb <= lim (buffers hold >= 16 bytes)
 #ifdef HMSE_DIAG
@@ -936,7 +949,7 @@ static uint32_t* const g_ifl_trace = nullptr;
 
 // 0 = choose by stream count, 1 = one stream per wavefront, 2 = one stream per lane
 static int g_ifl_mode = 0;
-constexpr uint64_t HMSE_INFLATE_WIDE_MIN = 32768;
+constexpr uint64_t HMSE_INFLATE_WIDE_MIN = 49152;
 extern "C" int hmse_l1_inflate_mode(int mode) {
   if (mode < 0 || mode > 2) return HMSE_EINVAL;
   g_ifl_mode = mode;

@@ -241,7 +241,7 @@ int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, const uint64
                     uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /*
- * Which decoder hmse_l1_inflate launches.  0 (default): by stream count — one stream per wavefront below 32768 streams
+ * Which decoder hmse_l1_inflate launches.  0 (default): by stream count — one stream per wavefront below 49152 streams
  * (a call lasts about as long as its longest stream), one stream per LANE from there on (four times the throughput
  * once the chip's 65 536 lanes are fed).  1 / 2 force the first / second.  Results are identical; process-wide.
  * No reference counterpart: mz_inflate (README.md:2397-2400) decodes one stream per call on one core.

@@ -4,7 +4,9 @@ reassembles to the input."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hmse_amd import IngestConfig, corpus, ingest, ops, read
+from hmse_amd import IngestConfig, _lib, corpus, ingest, ops, read
+if os.environ.get("HMSE_LIB"):   # an experimental build of the library (same ABI)
+    _lib.HIP_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmse_amd", "csrc", os.environ["HMSE_LIB"])
 
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 prof = sys.argv[2] if len(sys.argv) > 2 else "wikipedia"
