@@ -386,9 +386,11 @@ __device__ __forceinline__ uint64_t load8_at(const uint8_t* base, uint64_t off, 
 // trips, header rounds, cycles in publish / header / poll / decode / memory cluster, lane-trips that decoded a token
 #define LK_T0() uint64_t t_ = __builtin_readcyclecounter()
 #define LK_LAP(i) do { const uint64_t u_ = __builtin_readcyclecounter(); cyc[i] += u_ - t_; t_ = u_; } while (0)
+#define LK_SUB(i) do { const uint64_t u_ = __builtin_readcyclecounter(); cyc[i] += u_ - ts_; ts_ = u_; } while (0)
 #else
 #define LK_T0() do { } while (0)
 #define LK_LAP(i) do { } while (0)
+#define LK_SUB(i) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   uint32_t lit = 0;                                                   // 0x100 | literal decoded this trip
 
 #ifdef HMSE_DIAG
-  uint64_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (uint32_t trip = 0; trip < 0x7FFFFFF0u; trip++) {
     LK_T0();
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
     if (n_wait >= HDR_MIN || (n_wait != 0 && m_run == 0)) {
 #ifdef HMSE_DIAG
       cyc[1]++;
+      uint64_t ts_ = __builtin_readcyclecounter();
 #endif
       if (st == ST_WAIT) {
         if (need_pull) {
@@ -485,6 +488,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
             budget = bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)bits;
           }
         }
+        LK_SUB(12);
         if (st == ST_WAIT && bad) st = ST_FIN;
         if (st == ST_WAIT) {
           // -- block header (RFC 1951 §3.2.3) --
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
                   }
                 }
             }
+            LK_SUB(13);
             // -- code lengths of the two alphabets.  They are needed twice, in order (counted per length now, placed by
             // rank afterwards): eight 4-bit lengths per word go through a 40-register FIFO — registers cannot be indexed
             // by a lane, but a queue only ever moves by one.  Counts per length live in packed registers as well:
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
               if ((LF[7] & 0xFu) == 0) bad = true;
             }
             if (staged) { p = B0 + lp; staged = false; }                 // back to the stream itself
+            LK_SUB(14);
             uint64_t nxl[4] = {0, 0, 0, 0}, nxd[2] = {0, 0};             // running offset per length (the counts' layout)
             if (!bad) {
               // -- literal/length decode words --
@@ -705,6 +711,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
 #undef LF_PUSH
 #undef LREFILL
           }
+          LK_SUB(15);
           if (bad) { st = ST_FIN; rem = 0; pn = 0; oc = 0; }
           else st = ST_DEC;
         }
@@ -734,6 +741,10 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
     // ---- 4. one token ----------------------------------------------------------------------------------------------
 #ifdef HMSE_DIAG
     cyc[7] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DEC && !blocked && rem == 0 && !eob));
+    cyc[8] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DEC && !blocked && rem != 0));   // copying a long match
+    cyc[9] += (uint64_t)__builtin_popcountll(__ballot(st == ST_WAIT));                           // waiting for a header round
+    cyc[10] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DONE));                          // out of work
+    cyc[11] += (uint64_t)__builtin_popcountll(__ballot(st == ST_DEC && blocked));                // waiting for a base chunk
 #endif
     const bool dec = st == ST_DEC && !blocked && rem == 0;
     if (dec && eob) {                                                   // end of a block: rare, a real branch
@@ -904,7 +915,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   }
 #ifdef HMSE_DIAG
   if (a.trace && lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)a.trace + i, (unsigned long long)cyc[i]);
+    for (int i = 0; i < 16; i++) atomicAdd((unsigned long long*)a.trace + i, (unsigned long long)cyc[i]);
 #endif
 #undef LB
 #undef HREFILL
