@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
   uint32_t pback = 0;                                                 // fix-up of a load pulled back from a buffer's end
   uint64_t w0 = 0, w1 = 0; uint32_t wo = 0;                           // 16 stream bytes; byte p of the stream at offset wo
   uint64_t ob0 = 0, ob1 = 0; uint32_t oc = 0, opos = 0;   // output bytes [opos, opos + oc) not stored yet
+  uint32_t litA = 0;                                                  // 0x100 | short-code literal taken in front of it (slot A)
   uint32_t lit = 0;                                                   // 0x100 | literal decoded this trip
 
 #ifdef HMSE_DIAG
@@ -617,20 +618,25 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
                 if (s > 18 || budget-- == 0) { bad = true; break; }
               }
               if (i + rep > tot) { bad = true; break; }
-              for (uint32_t r = 0; r < rep; r++, i++) {
-                nw |= val << (4 * (i & 7u));
-                if ((i & 7u) == 7u) { LF_PUSH(nw); nw = 0; npush++; }
-                if (val) {
-                  if (i < nlit) {
-                    const uint64_t inc = 1ull << (16 * (val & 3u));
-                    const uint32_t r4 = val >> 2;
+              // the run's counts in one step (a per-symbol loop would run to the longest run among the lanes of the round:
+              // a 138-symbol run of zeros in one lane made all of them spin), then its nibbles a word at a time
+              if (val) {
+                const uint32_t n_lit = i >= nlit ? 0u : (nlit - i < rep ? nlit - i : rep);
+                const uint32_t n_lo = i >= 256 ? 0u : (256 - i < rep ? 256 - i : rep);
+                const uint32_t sh16 = 16 * (val & 3u);
+                const uint64_t inc_lit = (uint64_t)n_lit << sh16, inc_lo = (uint64_t)n_lo << sh16;
+                const uint32_t r4 = val >> 2;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { lc[q] += r4 == (uint32_t)q ? inc : 0ull; nl[q] += (r4 == (uint32_t)q && i < 256) ? inc : 0ull; }
-                  } else {
-                    const uint64_t inc = 1ull << (8 * (val & 7u));
-                    dc[0] += val < 8 ? inc : 0ull; dc[1] += val >= 8 ? inc : 0ull;
-                  }
-                }
+                for (int q = 0; q < 4; q++) { lc[q] += r4 == (uint32_t)q ? inc_lit : 0ull; nl[q] += r4 == (uint32_t)q ? inc_lo : 0ull; }
+                const uint64_t incd = (uint64_t)(rep - n_lit) << (8 * (val & 7u));
+                dc[0] += val < 8 ? incd : 0ull; dc[1] += val >= 8 ? incd : 0ull;
+              }
+              while (rep) {
+                const uint32_t o = i & 7u, k = rep < 8 - o ? rep : 8 - o;
+                const uint32_t fill = k == 8 ? 0xFFFFFFFFu : ((1u << (4 * k)) - 1u) << (4 * o);
+                nw |= (val * 0x11111111u) & fill;
+                i += k; rep -= k;
+                if ((i & 7u) == 0) { LF_PUSH(nw); nw = 0; npush++; }
               }
               prev = val;
             }
@@ -759,6 +765,24 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       // the one its symbol selects (with 64 independent streams every path is taken in every trip anyway; as nested ifs
       // the step was half scalar mask bookkeeping and branches).  A lane whose symbol is no length consumes 0 extra bits
       // and a 0-bit distance code.
+      // Slot A: two thirds of all tokens are literals, and the frequent ones have short codes.  A literal whose code has
+      // at most 9 bits is taken here on top (9 of the 15 compare/select pairs), provided 48 bits remain for the full
+      // token step below, which then decodes the token AFTER it: ~1.5 tokens per trip instead of 1.
+      {
+        const uint32_t XA = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;
+        const uint32_t xk = (XA << 16) | 0xFFFFu;
+        uint32_t sa = P[0], sq = Q[0];
+#pragma unroll
+        for (int j = 1; j <= 8; j++) { const bool ge = xk >= P[j]; sa = ge ? P[j] : sa; sq = ge ? Q[j] : sq; }
+        const uint32_t la = sq >> 9;                                     // 1..9, the code's length if xk < P[9]
+        const uint32_t ia = ((sa & 0xFFFFu) + ((XA - (sa >> 16)) >> (15 - la))) & 0x1FFu;
+        const uint32_t ba = LB(W_LSYM * 4 + (ia < 288 ? ia : 0));
+        const bool take = xk < P[9] && ia < (sq & 0x1FFu) && la + 48 <= n && pos < L && budget > 1;
+        litA = take ? ba | 0x100u : 0u;
+        const uint32_t da = take ? la : 0u;
+        acc >>= da; n -= da;
+        pos += take ? 1u : 0u; budget -= take ? 1u : 0u;
+      }
       uint32_t err = budget == 0 ? 1u : 0u;
       budget -= 1;
       const uint32_t X = __builtin_bitreverse32((uint32_t)acc & 0x7FFFu) >> 17;   // the window was refilled in step 5
@@ -805,7 +829,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
         rem = is_len ? len : 0u;
         cq = is_len ? pos : cq; D = is_len ? dist : D; span = is_len ? dist : span; stored = is_len ? 0u : stored;
         pos += is_lit ? 1u : is_len ? len : 0u;
-      } else { bad = 1; st = ST_FIN; rem = 0; pn = 0; oc = 0; }
+      } else { bad = 1; st = ST_FIN; rem = 0; pn = 0; oc = 0; litA = 0; }
     }
     LK_LAP(5);
     // ---- 5. every memory operation of the trip, in one cluster: what it waits for was issued a whole trip ago ----------
@@ -836,7 +860,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       p += adv; n += adv * 8u; wo += adv;
     }
 #ifdef HMSE_DIAG
-    if (a.dflags & 1u) lit = 0;
+    if (a.dflags & 1u) { lit = 0; litA = 0; }
     if (a.dflags & 2u) pn = 0;
 #endif
     if (pn && pback) {   // the load was pulled back from the end of the buffer: drop the bytes in front
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       else { pc0 = (pc0 >> t) | (pc1 << (64 - t)); pc1 >>= t; }
       pback = 0;
     }
-    const uint32_t m_in = pn + (lit ? 1u : 0u);
+    const uint32_t m_in = pn + (litA ? 1u : 0u) + (lit ? 1u : 0u);
     if (oc != 0 && (force || oc + m_in > 16)) {
       uint8_t* const d = outp + opos;
       if (opos + 16 <= L) { __builtin_memcpy(d, &ob0, 8); __builtin_memcpy(d + 8, &ob1, 8); }
@@ -879,6 +903,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       oc += (cnt);                                                                                           \
     } while (0)
     OB_APPEND(pc0, pc1, pn); pn = 0;
+    { const uint64_t lb = litA & 0xFFu; OB_APPEND(lb, 0ull, (litA ? 1u : 0u)); litA = 0; }
     { const uint64_t lb = lit & 0xFFu; OB_APPEND(lb, 0ull, (lit ? 1u : 0u)); lit = 0; }
 #undef OB_APPEND
     if (fill && wo > 8) {                                               // fewer than 8 bytes left in the window
@@ -888,7 +913,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       __builtin_memcpy(&w0, a.streams + q, 8); __builtin_memcpy(&w1, a.streams + q + 8, 8);
     }
     if (rem) {
-      uint32_t nb = rem < 15 ? rem : 15;
+      uint32_t nb = rem < 14 ? rem : 14;                                 // + two literals of the next trip <= 16
       const uint8_t* s; const uint8_t* lim;
       bool clash = false;
       if (stored) { s = a.streams + sp; lim = a.streams + a.streams_bytes; }
