@@ -179,13 +179,21 @@ def main():
             cpu = cpu_baseline(host, a.cpu_sample_mib)
         except Exception as e:  # noqa: BLE001 — the baseline leg must not lose the GPU measurement
             cpu = {"error": repr(e)}
+    # HMSE_BENCH_REHEARSE=1: every rank on GPU 0, exchanges over gloo — the N-rank control flow (sharding, the digest
+    # exchange, max-over-ranks timing, the rank-0 JSON line) on a one-GPU box; never a measurement
+    rehearse = os.environ.get("HMSE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # HMSE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-gather, reductions) even at world size 1
     distributed = world > 1 or os.environ.get("HMSE_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     t0 = time.time()
     data = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize()
@@ -218,7 +226,7 @@ def main():
     dt = time.perf_counter() - t0
     lib.hmse_profile_enable(0)
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -333,7 +341,7 @@ def main():
                            (1, "dictionary DEFLATE level-9 profile" if cfg.layers & 8 else "DEFLATE level-9 profile")) if cfg.layers & bit)
                                    + f") over {tot['bytes'] / 1e9:.2f} GB {a.corpus}",
                        "total_bytes": tot["bytes"], "seg_size": seg, "sharding": f"{world} x contiguous 4 MiB-segment runs",
-                       "collective": "all_gather(digests) over RCCL" if distributed else "none"},
+                       "collective": ("all_gather(digests) over gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else "all_gather(digests) over RCCL") if distributed else "none"},
             "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4), "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4),
             "lsh_hit_rate": round(tot["lsh_hit_rate"], 4), "delta_rate": round(tot["delta_rate"], 4), "chunks": tot["chunks"],
             "frac_hbm_read_roofline": round(tot["bytes"] * a.steps / dt / 1e9 / (HBM_PEAK_GBPS * world), 6),

@@ -55,15 +55,19 @@ def gather_digests(digests: torch.Tensor, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = digests.device
-    n_loc = torch.tensor([digests.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    # the collective runs where the backend moves bytes: on the device for RCCL, through host memory for gloo (the CPU
+    # tests, and a rehearsal of an N-rank run with every rank on one GPU: bench.py HMSE_BENCH_REHEARSE)
+    xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    n_loc = torch.tensor([digests.shape[0]], dtype=torch.int64, device=xdev)
+    counts = torch.empty(world, dtype=torch.int64, device=xdev)
     dist.all_gather_into_tensor(counts, n_loc, group=group)
     cl = counts.tolist()
     mx = max(cl)
-    padded = torch.zeros((mx, 32), dtype=torch.uint8, device=dev)
-    padded[: digests.shape[0]] = digests
-    allp = torch.empty((world * mx, 32), dtype=torch.uint8, device=dev)
+    padded = torch.zeros((mx, 32), dtype=torch.uint8, device=xdev)
+    padded[: digests.shape[0]] = digests.to(xdev)
+    allp = torch.empty((world * mx, 32), dtype=torch.uint8, device=xdev)
     dist.all_gather_into_tensor(allp, padded, group=group)
+    allp = allp.to(dev)
     if all(c == mx for c in cl):
         alld = allp
     else:
