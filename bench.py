@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--layers", default="full", help="ablation preset (hmse_amd.config.ABLATIONS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-l4", action="store_true",
+                    help="N > 1: base selection over all shards (signature all-gather + cross-GPU base fetch) instead of shard-local; "
+                         "the stored bytes are then those of the 1-GPU run")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample (0 = 4 MiB x 2 x cores, <= 256 MiB)")
     return ap.parse_args()
 
@@ -202,7 +205,7 @@ def main():
     lib = _lib.hip_lib()
 
     def step():
-        return ingest.ingest_shard(data, cfg, seg_off, distributed=distributed, want_stats=False)
+        return ingest.ingest_shard(data, cfg, seg_off, distributed=distributed, want_stats=False, global_l4=a.global_l4 and distributed)
 
     def barrier():
         torch.cuda.synchronize()
@@ -282,7 +285,10 @@ def main():
     # read path, outside the timed region: every stored record is inflated on the GPU and its SHA-256
     # re-checked; on one GPU the whole corpus is also reassembled (pointers included) and compared byte for byte
     read_info = None
-    if res.streams is not None and res.digests is not None and os.environ.get("HMSE_BENCH_NO_VERIFY") != "1":
+    remote_dicts = a.global_l4 and distributed   # records may then name dictionaries stored on other ranks: no per-rank read-back/manifest
+    if remote_dicts:
+        read_info = {"scope": "skipped: with --global-l4 a record's dictionary may be stored on another rank (read.reconstruct_shards decodes all shards together)"}
+    elif res.streams is not None and res.digests is not None and os.environ.get("HMSE_BENCH_NO_VERIFY") != "1":
         from hmse_amd import read
         for s in (16, 17):
             lib.hmse_profile_read(s, None, None, 1)
@@ -311,7 +317,7 @@ def main():
 
     # the product's output: the shard's manifest records, packed on the GPU (outside the timed region, reported beside it)
     manifest_info = None
-    if res.streams is not None and os.environ.get("HMSE_BENCH_NO_MANIFEST") != "1":
+    if res.streams is not None and os.environ.get("HMSE_BENCH_NO_MANIFEST") != "1" and not remote_dicts:
         from hmse_amd import manifest
         sb = res.shard_bases
         manifest.pack_manifest_device(res, rank, world if sb else 1)   # warm-up (allocator, first launch)
@@ -341,7 +347,7 @@ def main():
                            (1, "dictionary DEFLATE level-9 profile" if cfg.layers & 8 else "DEFLATE level-9 profile")) if cfg.layers & bit)
                                    + f") over {tot['bytes'] / 1e9:.2f} GB {a.corpus}",
                        "total_bytes": tot["bytes"], "seg_size": seg, "sharding": f"{world} x contiguous 4 MiB-segment runs",
-                       "collective": ("all_gather(digests) over gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else "all_gather(digests) over RCCL") if distributed else "none"},
+                       "collective": ("all_gather(digests) over gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else ("all_gather(digests) + all_gather(signatures) + all_to_all(base chunks) over RCCL" if a.global_l4 else "all_gather(digests) over RCCL")) if distributed else "none"},
             "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4), "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4),
             "lsh_hit_rate": round(tot["lsh_hit_rate"], 4), "delta_rate": round(tot["delta_rate"], 4), "chunks": tot["chunks"],
             "frac_hbm_read_roofline": round(tot["bytes"] * a.steps / dt / 1e9 / (HBM_PEAK_GBPS * world), 6),

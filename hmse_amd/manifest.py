@@ -77,6 +77,10 @@ def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
         raise ops.HmseError(-1, "the manifest is packed on the GPU: the ShardResult must live in HBM")
     if res.streams is None:
         raise ops.HmseError(-1, "the manifest needs the L1 layer's streams")
+    if getattr(res, "base_global", None) is not None and bool(((res.base_global >= 0) & (res.base < 0)).any()):
+        # the 8-byte DeltaChunk header (README.md:2182-2189) names its base by an LBA of the SAME blob: a record whose
+        # dictionary lives on another shard has no on-disk form yet (ingest_shard(global_l4=True) is an ingest-side feature)
+        raise ops.HmseError(-1, "records with dictionaries on other shards cannot be packed into a per-shard manifest")
     dev = res.cuts.device
     n = res.cuts.numel() - 1
     u = res.uniq_ids.numel()

@@ -26,6 +26,8 @@ def reconstruct_shard(res, verify: bool = True) -> torch.Tensor:
     lens = cuts[1:] - cuts[:-1]
     if res.streams is None:
         raise ReadError("reconstruct_shard needs the L1 layer's streams")
+    if getattr(res, "base_global", None) is not None and bool(((res.base_global >= 0) & (res.base < 0)).any()):
+        raise ReadError("records of this shard use dictionaries stored on other shards: read.reconstruct_shards decodes all shards together")
     raw, raw_off, _ = ops.l1_inflate(res.streams, res.stream_off, res.kind, res.base, lens[res.uniq_ids])
     slot_of = torch.full((n_chunks,), -1, dtype=torch.int64, device=dev)
     slot_of[res.uniq_ids] = torch.arange(res.uniq_ids.numel(), dtype=torch.int64, device=dev)
@@ -38,6 +40,45 @@ def reconstruct_shard(res, verify: bool = True) -> torch.Tensor:
     if verify and res.digests is not None:
         verify_digests(data, cuts, res.digests)
     return data
+
+
+def reconstruct_shards(results: list, verify: bool = True) -> list:
+    """Inverse of a sharded ingest whose records may use dictionaries stored on OTHER shards (ingest_shard(global_l4=True)):
+    the stored records of all shards are inflated in ONE call, in global stored-chunk order (= rank order), so that a
+    DELTA record's dictionary — named by its global stored-chunk index — is any earlier record; then every shard's chunks
+    are laid out from the slots their first occurrences name.  Returns the shards' data tensors, in order."""
+    dev = results[0].cuts.device
+    u_counts = [int(r.uniq_ids.numel()) for r in results]
+    u_bases = [sum(u_counts[:i]) for i in range(len(results))]
+    lens_u, offs, run = [], [], 0
+    for r in results:
+        if r.streams is None:
+            raise ReadError("reconstruct_shards needs the L1 layer's streams")
+        ln = r.cuts[1:] - r.cuts[:-1]
+        lens_u.append(ln[r.uniq_ids]); offs.append(r.stream_off[:-1] + run); run += int(r.streams.numel())
+    streams = torch.cat([r.streams for r in results])
+    stream_off = torch.cat(offs + [torch.tensor([run], dtype=torch.int64, device=dev)])
+    kind = torch.cat([r.kind for r in results])
+    base = torch.cat([r.base_global if r.base_global is not None else torch.where(r.base >= 0, r.base + ub, r.base)
+                      for r, ub in zip(results, u_bases)])
+    raw, raw_off, _ = ops.l1_inflate(streams, stream_off, kind, base, torch.cat(lens_u))
+    # global chunk index -> global stored-chunk slot (first occurrences only)
+    n_global = results[0].n_global
+    slot_of_global = torch.full((n_global,), -1, dtype=torch.int64, device=dev)
+    for r, ub in zip(results, u_bases):
+        slot_of_global[r.chunk_base + r.uniq_ids] = torch.arange(ub, ub + r.uniq_ids.numel(), dtype=torch.int64, device=dev)
+    out = []
+    for r in results:
+        n_chunks = r.cuts.numel() - 1
+        fo = r.first_occ if r.first_occ is not None else torch.arange(r.chunk_base, r.chunk_base + n_chunks, dtype=torch.int64, device=dev)
+        slots = slot_of_global[fo]
+        if bool((slots < 0).any()):
+            raise ReadError("a first occurrence is not a stored chunk of any shard")
+        d = ops.read_assemble(r.cuts, slots, raw_off, raw)
+        if verify and r.digests is not None:
+            verify_digests(d, r.cuts, r.digests)
+        out.append(d)
+    return out
 
 
 def verify_stored(res) -> int:

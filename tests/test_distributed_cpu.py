@@ -57,3 +57,56 @@ def test_gather_digests_and_global_dedup_two_ranks(orc):
     fo_single, rc_single = orc.dedup(orc.sha256_chunks(data, whole))
     assert np.array_equal(fo_sharded, fo_single) and np.array_equal(rc_sharded, rc_single)
     assert (fo_sharded[len(dg[0]):] < len(dg[0])).sum() > 50          # cross-shard pointers exist
+
+
+def _fetch_worker(rank, world, port, shards, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hmse_amd import ingest
+    data, cuts, uniq = (torch.from_numpy(x) for x in shards[rank][:3])
+    req = torch.from_numpy(shards[rank][3])
+
+    def gather(out_cuts, cid, cuts_, data_):      # the HIP gather (hmse_read_assemble) restated for the CPU test
+        return torch.cat([data_[int(cuts_[c]): int(cuts_[c + 1])] for c in cid.tolist()]) if cid.numel() else data_[:0]
+    u_bases = [0, len(shards[0][2]), len(shards[0][2]) + len(shards[1][2])]
+    got, lens = ingest.fetch_chunks(req, u_bases, data, cuts, uniq, gather=gather)
+    out_q.put((rank, got.numpy().copy(), lens.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cross_rank_base_fetch_three_ranks():
+    """The exchange behind ingest_shard(global_l4=True): every rank asks the owners for the stored chunks it needs as
+    dictionaries (global stored-chunk ids, ascending) and gets their bytes back in request order — three all-to-alls,
+    uneven splits, a rank that asks for nothing, a rank nobody asks."""
+    rng = np.random.default_rng(11)
+    shards, stored = [], []
+    for r in range(3):
+        lens = rng.integers(1, 4000, 40 + 7 * r)
+        cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        data = rng.integers(0, 256, int(cuts[-1]), dtype=np.uint8)
+        uniq = np.sort(rng.choice(len(lens), 25 + r, replace=False)).astype(np.int64)     # the chunks this rank stores
+        shards.append([data, cuts, uniq, None])
+        stored += [data[cuts[c]: cuts[c + 1]] for c in uniq]
+    ub = [0, 25, 51, 78]
+    reqs = [np.array([30, 31, 60, 77], np.int64),           # rank 0 needs chunks of ranks 1 and 2
+            np.zeros(0, np.int64),                           # rank 1 needs nothing
+            np.array([0, 24, 25, 50], np.int64)]             # rank 2 needs chunks of ranks 0 and 1 (nobody asks rank 2's own last chunks twice)
+    for r in range(3):
+        shards[r][3] = reqs[r]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fetch_worker, args=(r, 3, port, shards, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(3)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, payload, lens in got:
+        want = [stored[g] for g in reqs[rank]]
+        assert lens.tolist() == [len(w) for w in want]
+        assert np.array_equal(payload, np.concatenate(want) if want else np.zeros(0, np.uint8))
+    assert ub[3] == len(stored)

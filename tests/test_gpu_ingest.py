@@ -224,6 +224,40 @@ def test_two_shard_store_on_one_gpu_merges_and_reads_back(orc, dev):
     assert torch.equal(read.read_store(manifest.merge_manifests([manifest.build_manifest(one)]), dev), torch.from_numpy(data).to(dev))
 
 
+def test_global_l4_three_shards_equal_the_one_shard_run(dev):
+    """Cross-shard base selection (SURVEY.md §8e last sentence, §8f-3), without a second GPU: three shards ingested with
+    global_l4 — signatures 'all-gathered', one LSH over all stored chunks, remote base chunks fetched and appended as ghost
+    chunks — give the streams, kinds and bases of the ONE-shard run, bit for bit; some dictionaries really are remote;
+    all shards decode together (a DELTA's dictionary may be another shard's record) to the input; per-shard readers and
+    the manifest packer refuse such a shard."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest, manifest, ops, read
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(12 << 20, seed=42)
+    d = torch.from_numpy(data).to(dev)
+    one = ingest.ingest_shard(d, cfg)
+    shards = [d[: 4 << 20], d[4 << 20: 8 << 20], d[8 << 20:]]
+    res = ingest.ingest_shards_local(shards, cfg, global_l4=True)
+    assert torch.equal(torch.cat([r.streams for r in res]), one.streams)
+    assert torch.equal(torch.cat([r.kind for r in res]), one.kind)
+    assert torch.equal(torch.cat([r.base_global for r in res]), one.base)
+    assert torch.equal(torch.cat([r.band_keys for r in res]), one.band_keys)
+    n_remote = sum(int(((r.base_global >= 0) & (r.base < 0)).sum()) for r in res)
+    n_remote_delta = sum(int(((r.base_global >= 0) & (r.base < 0) & (r.kind == 2)).sum()) for r in res)
+    assert n_remote > 20 and n_remote_delta > 10
+    back = read.reconstruct_shards(res, verify=True)
+    assert torch.equal(torch.cat(back), d)
+    # shard-local L4 (the default) stores more: its CF is what global L4 improves on
+    loc = ingest.ingest_shards_local(shards, cfg)
+    assert sum(int(r.streams.numel()) for r in loc) > int(one.streams.numel())
+    assert torch.equal(torch.cat(read.reconstruct_shards(loc)), d)               # the joint reader also takes local-base shards
+    late = next(r for r in res if bool(((r.base_global >= 0) & (r.base < 0)).any()))
+    with pytest.raises(read.ReadError):
+        read.reconstruct_shard(late)
+    with pytest.raises(ops.HmseError):
+        manifest.build_manifest(late, 1, 3)
+
+
 def test_distributed_ingest_world_size_1_runs_rccl(dev):
     """ingest_shard(distributed=True) under the driver: RCCL init, the count and digest all-gathers and the gathered dedupe
     run at world size 1 and give the single-shard result (the N > 1 exchange itself is covered by the gloo tests)."""
