@@ -16,6 +16,33 @@
 
 constexpr int MH_DEFAULT_VARIANT = 5;
 
+// MEMO TABLE (round 2).  The 128 hashes of a shingle are a pure function of its 4 bytes, text re-uses its 4-grams
+// endlessly (256 MiB of the wiki-synth corpus hold 265 k distinct ones, every 8 KiB chunk ~4.4 k of them), and a shingle
+// can only lower sig[s] if its hash for seed s is small.  So the first workgroup that meets a shingle computes its 128
+// hashes (the tail loop below, as before) and records in a global table which seeds fall below TAU = 2^23 — none for
+// 78 % of all shingles, exactly one for 19.5 %, more for 2.6 % ("uncacheable": always computed in full) — as ONE 8-byte
+// entry {R, payload}, written by one 64-bit CAS.  Later workgroups look every distinct shingle up (one 8-byte gather;
+// 270 G gathers/s while the table stays L2-resident, tools/ubench/gmem_gather.hip) and run the tail loop only over the
+// misses.  EXACT: a seed whose minimum over the looked-up and the computed shingles is below TAU has its true minimum
+// (every hash below TAU is in the table or was computed); the few seeds that end at or above TAU (0.02 % for a chunk of
+// 4.4 k shingles, 2 % for one of 2 k; with TAU = 2^22 this re-evaluation was a quarter of the kernel) are re-evaluated over all distinct shingles of the chunk.  The table is read-only inside a launch as
+// far as correctness goes (a stale or missing entry is a miss); hmse_l4_minhash clears it per call and issues launches
+// of growing size, so that all but the first few hundred chunks meet a warm table whatever the caches of the other XCDs
+// hold.  Capacity 2^18 slots (2 MiB: the table has to stay L2-resident beside the streaming corpus — 2^17: 24.5 ms, 2^18: 21.7,
+// 2^19: 28.4, 2^20: 27.3 ms per 2 GiB), filled to one half with the first 131 k distinct shingles met (the frequent ones
+// come early), then no more inserts: data without repeating 4-grams (random
+// bytes) costs what it cost before plus the lookups of the first MH_SAMPLE shingles per wavefront, after which the
+// wavefront stops looking.
+constexpr uint32_t MH_TAU = 1u << 23;      // payload: value [22:0], seed [29:23]
+constexpr uint32_t MH_P_NONE = 1u << 30, MH_P_UNC = 1u << 31;
+#ifndef HMSE_MH_MEMO_BITS
+#define HMSE_MH_MEMO_BITS 18
+#endif
+constexpr int MH_MEMO_BITS = HMSE_MH_MEMO_BITS;
+constexpr uint64_t MH_MEMO_EMPTY = ~0ull;
+constexpr uint32_t MH_SAMPLE = 256;     // lookups after which a wavefront with < 1/4 hits stops looking (per pass)
+struct MhMemo { unsigned long long* tab; uint32_t* count; uint32_t bits; uint32_t cap; uint32_t probe; };   // probe: diagnostic build only
+
 constexpr int MH_TBITS = 14;
 constexpr int MH_SLOTS = 1 << MH_TBITS;   // 16384 x 4 B = 64 KiB
 constexpr int MH_SUB = MH_SLOTS * 3 / 4;  // shingles per pass: load factor <= 0.75 even if all are distinct (text: ~0.4);
@@ -59,12 +86,14 @@ template <int NT, int V>
 __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                         const uint64_t* __restrict__ cuts,
                                                         const uint64_t* __restrict__ chunk_ids, uint64_t n_sel,
-                                                        uint32_t seed_base, uint32_t* __restrict__ sig, const uint64_t* __restrict__ st) {
+                                                        uint32_t seed_base, uint32_t* __restrict__ sig, const uint64_t* __restrict__ st,
+                                                        MhMemo memo, uint64_t sel0) {
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[MH_SLOTS];
   __shared__ uint32_t s_sig[NT / 64][128];
-  __shared__ uint32_t s_flag;
+  __shared__ uint32_t s_min[128], s_pass[128], s_glob[128], s_unres[128];
+  __shared__ uint32_t s_flag, s_nun, s_any;
   if (st) { chunk_ids += st[SB_U_OLD]; sig += 128 * st[SB_U_OLD]; n_sel = st[SB_U_NEW]; }   // captured chain: this batch's stored chunks
-  const uint64_t sel = blockIdx.x;
+  const uint64_t sel = sel0 + blockIdx.x;
   if (sel >= n_sel) return;
   const uint32_t t = threadIdx.x, lane = lane_id(), w = t >> 6;
   const uint64_t c = chunk_ids ? chunk_ids[sel] : sel;
@@ -72,9 +101,11 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
   const uint64_t len = cuts[c + 1] - start;
   const uint64_t nsh = len >= 4 ? len - 3 : 0;
   const uint32_t sr0 = rotl32(seed_base + lane, 13), sr1 = rotl32(seed_base + lane + 64, 13);
-  uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
   constexpr int PART = MH_SLOTS / (NT / 64);  // each wavefront compacts and streams its own part of the table
   uint32_t* q = s_tab + w * PART;
+  const bool ins = memo.tab && *memo.count < memo.cap;   // room for new entries (read once: the count only grows)
+  if (t < 128) { s_glob[t] = 0xFFFFFFFFu; s_min[t] = 0xFFFFFFFFu; }
+  if (t == 0) { s_nun = 0; s_any = 0; }
 
   for (uint64_t sub0 = 0; sub0 < nsh; sub0 += MH_SUB) {
     const uint32_t cnt = (uint32_t)((nsh - sub0) < (uint64_t)MH_SUB ? (nsh - sub0) : (uint64_t)MH_SUB);
@@ -107,70 +138,207 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       if (valid) q[wr + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = v;
       wr += (uint32_t)__builtin_popcountll(m);
     }
-    // stream the distinct R values through the 2 seeds of this lane
-    const uint32_t wr4 = V == 2 ? 0u : (wr & ~3u);
-    if (V == 2) wr = 0;
-    for (uint32_t i = 0; i < wr4; i += 4) {
-      const uint4 kv = *(const uint4*)(q + i);
+    // ---- memo lookups: every distinct shingle of this wavefront's part; what the table cannot answer goes to the top of
+    // the part (the todo list), which the tail loop below then streams instead of the whole part
+    uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;   // this pass, this wavefront: minima over the computed shingles
+    const uint32_t* tp = q;
+    uint32_t nt = wr;
+    if (V == 1 && memo.tab && wr * 2 <= (uint32_t)PART) {
+      uint32_t looked = 0, hits = 0, i0 = 0;
+      nt = 0;
+      const uint32_t mask = (1u << memo.bits) - 1u;
+      for (; i0 < wr; i0 += 256) {          // four entries per lane: their first probes are in flight together
+        uint32_t R[4]; unsigned long long e[4]; uint32_t sl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t i = i0 + 64 * u + lane;
+          R[u] = i < wr ? q[i] : 0u;
+          sl[u] = (R[u] * 0x9E3779B1u) >> (32 - memo.bits);
+#ifdef HMSE_DIAG
+          if (memo.probe & 2u) e[u] = ((unsigned long long)MH_P_NONE << 32) | R[u]; else   // timing probe: no table reads, wrong signatures
+#endif
+          e[u] = i < wr ? memo.tab[sl[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t i = i0 + 64 * u + lane;
+          const bool valid = i < wr;
+          bool todo = false;
+          if (valid) {
+            unsigned long long ee = e[u];
+            if ((uint32_t)ee != R[u] && ee != MH_MEMO_EMPTY) {
+              uint32_t s2 = (sl[u] + 1) & mask; ee = memo.tab[s2];
+              if ((uint32_t)ee != R[u] && ee != MH_MEMO_EMPTY) { s2 = (s2 + 1) & mask; ee = memo.tab[s2]; }
+            }
+            if ((uint32_t)ee == R[u]) {
+              const uint32_t pl = (uint32_t)(ee >> 32);
+              if (pl & MH_P_UNC) todo = true;
+              else if (!(pl & MH_P_NONE)) atomicMin(&s_min[(pl >> 23) & 127u], pl & (MH_TAU - 1u));
+            } else todo = true;
+          }
+          const uint64_t mt = __ballot(todo);
+          if (todo) q[PART - 1 - (nt + (uint32_t)__builtin_popcountll(mt & lanemask_lt()))] = R[u];
+          nt += (uint32_t)__builtin_popcountll(mt);
+          looked += (uint32_t)__builtin_popcountll(__ballot(valid));
+        }
+        hits = looked - nt;
+        if (looked >= MH_SAMPLE && hits * 4 < looked) { i0 += 256; break; }   // a cold or useless table: stop looking
+      }
+      for (; i0 < wr; i0 += 64) {      // (the rest of the part after giving up: all todo)
+        const uint32_t i = i0 + lane;
+        if (i < wr) q[PART - 1 - (nt + (i - i0))] = q[i];
+        nt += (wr - i0) < 64u ? (wr - i0) : 64u;
+      }
+      tp = q + PART - nt;
+      if (lane == 0) s_any = 1;
+#ifdef HMSE_DIAG
+      if (lane == 0 && (memo.probe & 4u)) { atomicAdd(memo.count + 1, looked); atomicAdd(memo.count + 2, nt); atomicAdd(memo.count + 4, wr); }   // tools/minhash_memo_stats.py
+#endif
+    }
+    // one computed shingle -> the table: which of its 128 hashes fall below TAU
+    auto memo_insert = [&](uint32_t R, uint32_t a0, uint32_t a1) {
+      const uint64_t b0 = __ballot(a0 < MH_TAU), b1 = __ballot(a1 < MH_TAU);
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(b0) + (uint32_t)__builtin_popcountll(b1);
+      uint32_t pl = MH_P_NONE;
+      if (cnt >= 2) pl = MH_P_UNC;
+      else if (cnt == 1) {
+        const uint32_t sl = b0 ? (uint32_t)__builtin_ctzll(b0) : (uint32_t)__builtin_ctzll(b1);
+        const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)(b0 ? a0 : a1), (int)sl);
+        pl = ((b0 ? sl : sl + 64u) << 23) | val;
+      }
+      if (lane == 0) {
+        const unsigned long long ent = ((unsigned long long)pl << 32) | R;
+        const uint32_t mask = (1u << memo.bits) - 1u;
+        uint32_t sl = (R * 0x9E3779B1u) >> (32 - memo.bits);
+        for (int pr = 0; pr < 3; pr++) {
+          const unsigned long long old = atomicCAS(&memo.tab[sl], MH_MEMO_EMPTY, ent);
+          if (old == MH_MEMO_EMPTY) { atomicAdd(memo.count, 1u); break; }
+          if ((uint32_t)old == R) break;
+          sl = (sl + 1) & mask;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // stream the todo list (without a table: the whole part) through the 2 seeds of this lane
+    if (V == 2) nt = 0;
+    uint32_t hd = (4u - ((uint32_t)(tp - q) & 3u)) & 3u;      // entries in front of the first 16-byte boundary
+    if (hd > nt) hd = nt;
+    for (uint32_t i = 0; i < hd; i++) {
+      const uint32_t R = tp[i];
+      const uint32_t a0 = murmur_tail<V>(R, sr0), a1 = murmur_tail<V>(R, sr1);
+      m0 = min(m0, a0); m1 = min(m1, a1);
+      if (ins) memo_insert(R, a0, a1);
+    }
+    const uint32_t n4 = hd + ((nt - hd) & ~3u);
+    for (uint32_t i = hd; i < n4; i += 4) {
+      const uint4 kv = *(const uint4*)(tp + i);
       const uint32_t a0 = murmur_tail<V>(kv.x, sr0), a1 = murmur_tail<V>(kv.x, sr1);
       const uint32_t b0 = murmur_tail<V>(kv.y, sr0), b1 = murmur_tail<V>(kv.y, sr1);
       const uint32_t c0 = murmur_tail<V>(kv.z, sr0), c1 = murmur_tail<V>(kv.z, sr1);
       const uint32_t d0 = murmur_tail<V>(kv.w, sr0), d1 = murmur_tail<V>(kv.w, sr1);
       m0 = min3u(min3u(m0, a0, b0), c0, d0);
       m1 = min3u(min3u(m1, a1, b1), c1, d1);
+      if (ins) { memo_insert(kv.x, a0, a1); memo_insert(kv.y, b0, b1); memo_insert(kv.z, c0, c1); memo_insert(kv.w, d0, d1); }
     }
-    for (uint32_t i = wr4; i < wr; i++) {
-      const uint32_t R = q[i];
-      m0 = min(m0, murmur_tail<V>(R, sr0));
-      m1 = min(m1, murmur_tail<V>(R, sr1));
+    for (uint32_t i = n4; i < nt; i++) {
+      const uint32_t R = tp[i];
+      const uint32_t a0 = murmur_tail<V>(R, sr0), a1 = murmur_tail<V>(R, sr1);
+      m0 = min(m0, a0); m1 = min(m1, a1);
+      if (ins) memo_insert(R, a0, a1);
     }
     if (w == 0 && s_flag) {  // the one R value that collides with the empty marker
       m0 = min(m0, murmur_tail<V>(MH_EMPTY, sr0));
       m1 = min(m1, murmur_tail<V>(MH_EMPTY, sr1));
     }
+    // ---- this pass's minima: computed (per wavefront) and looked up (s_min); seeds still at or above TAU where a table
+    // was consulted are re-evaluated over every distinct shingle of the pass
+    s_sig[w][lane] = m0;
+    s_sig[w][lane + 64] = m1;
+    __syncthreads();
+    if (t < 128) {
+      uint32_t v = s_min[t];
+#pragma unroll
+      for (int i = 0; i < NT / 64; i++) v = min(v, s_sig[i][t]);
+      s_pass[t] = v;
+      if (s_any && v >= MH_TAU) s_unres[atomicAdd(&s_nun, 1u)] = t;
+    }
+    __syncthreads();
+#ifdef HMSE_DIAG
+    const uint32_t nun = (memo.probe & 1u) ? 0u : s_nun;   // timing probe: no re-evaluation, wrong signatures
+#else
+    const uint32_t nun = s_nun;
+#endif
+#ifdef HMSE_DIAG
+    if (t == 0 && memo.tab && (memo.probe & 4u)) { atomicAdd(memo.count + 3, nun); atomicAdd(memo.count + 5, 1u); }
+#endif
+    for (uint32_t j = 0; j < nun; j++) {
+      const uint32_t sd = s_unres[j];
+      const uint32_t sr = rotl32(seed_base + sd, 13);
+      uint32_t lo = 0xFFFFFFFFu;
+      for (uint32_t i = lane; i < wr; i += 64) lo = min(lo, murmur_tail<V>(q[i], sr));
+      if (w == 0 && s_flag) lo = min(lo, murmur_tail<V>(MH_EMPTY, sr));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+      if (lane == 0) atomicMin(&s_pass[sd], lo);
+    }
+    __syncthreads();
+    if (t < 128) { s_glob[t] = min(s_glob[t], s_pass[t]); s_min[t] = 0xFFFFFFFFu; }
+    if (t == 0) { s_nun = 0; s_any = 0; }
     __syncthreads();
   }
-  s_sig[w][lane] = m0;
-  s_sig[w][lane + 64] = m1;
-  __syncthreads();
-  if (t < 128) {
-    uint32_t v = s_sig[0][t];
-#pragma unroll
-    for (int i = 1; i < NT / 64; i++) v = min(v, s_sig[i][t]);
-    sig[sel * 128 + t] = v;
-  }
+  if (t < 128) sig[sel * 128 + t] = s_glob[t];
 }
 
-size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t) { return 256; }
+// workspace: [0, 256) header (entry count), then the memo table
+size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t) { return 256 + ((size_t)8 << MH_MEMO_BITS); }
 
 extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
                                uint64_t n_sel, const hmse_cfg* cfg, uint32_t* sig, void* ws, size_t ws_bytes, void* stream_) {
-  (void)ws; (void)ws_bytes;
   if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
   if (n_sel == 0) return HMSE_OK;
   if (!data || !cuts || !sig) return HMSE_EINVAL;
   if (n_sel > 0x7FFFFFFFull) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
-  const dim3 grid((uint32_t)n_sel);
+  // the memo table lives in the caller's workspace and is cleared per call (a call's result and cost do not depend on
+  // what ran before); a workspace of the old size (256 bytes) simply runs without one
+  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, 1u << (MH_MEMO_BITS - 1), 0};
+#ifdef HMSE_DIAG
+  if (getenv("HMSE_MH_PROBE")) memo.probe = (uint32_t)atoi(getenv("HMSE_MH_PROBE"));   // 1 no re-evaluation, 2 no table reads, 4 counters
+#endif
+  if (ws && ws_bytes >= hmse_l4_minhash_workspace_bytes_impl(n_sel)) {
+    memo.count = (uint32_t*)ws;
+    memo.tab = (unsigned long long*)((uint8_t*)ws + 256);
+    HMSE_HIP(hipMemsetAsync(ws, 0, 256, stream));
+    HMSE_HIP(hipMemsetAsync(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream));
+  }
   PROF_BEGIN(HMSE_STAGE_L4_MINHASH, stream);
 #ifdef HMSE_DIAG
   // diagnostic build only (libhmse_hip_diag.so, tools/minhash_variants.py): threads per workgroup x instruction variant;
   // variants 6 and 7 are timing probes that return WRONG signatures, which is why none of this is in the product library
   static const int variant = getenv("HMSE_MH_VARIANT") ? atoi(getenv("HMSE_MH_VARIANT")) : MH_DEFAULT_VARIANT;
+  const dim3 grid((uint32_t)n_sel);
+  const MhMemo none{nullptr, nullptr, MH_MEMO_BITS, 0, 0};
   switch (variant) {
-    case 0: l4_minhash_kernel<256, 0><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
-    case 1: l4_minhash_kernel<256, 1><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
-    case 2: l4_minhash_kernel<512, 0><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
-    case 3: l4_minhash_kernel<512, 1><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
-    case 4: l4_minhash_kernel<1024, 0><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
-    case 6: l4_minhash_kernel<1024, 2><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;  // timing probe: no tail
-    case 7: l4_minhash_kernel<1024, 3><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;  // timing probe: no inserts
-    default: l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr); break;
+    case 0: l4_minhash_kernel<256, 0><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;
+    case 1: l4_minhash_kernel<256, 1><<<grid, dim3(256), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;
+    case 2: l4_minhash_kernel<512, 0><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;
+    case 3: l4_minhash_kernel<512, 1><<<grid, dim3(512), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;
+    case 4: l4_minhash_kernel<1024, 0><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;
+    case 6: l4_minhash_kernel<1024, 2><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;  // timing probe: no tail
+    case 7: l4_minhash_kernel<1024, 3><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, none, 0); PROF_END(HMSE_STAGE_L4_MINHASH, stream); HMSE_LAUNCH_CHECK(); return HMSE_OK;  // timing probe: no inserts
+    case 8: memo = none; break;   // the product kernel without its memo table
+    default: break;
   }
-#else
-  l4_minhash_kernel<1024, 1><<<grid, dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr);
 #endif
+  // launches of growing size: the first chunks fill the table, all later launches start from a warm one
+  uint64_t done = 0, step = memo.tab ? 256 : n_sel;
+  while (done < n_sel) {
+    const uint64_t cnt = (n_sel - done) < step ? (n_sel - done) : step;
+    l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cnt), dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, memo, done);
+    done += cnt;
+    step = step >= (1u << 18) ? n_sel : step * 4;
+  }
   PROF_END(HMSE_STAGE_L4_MINHASH, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
@@ -180,7 +348,8 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
 int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
                         const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream) {
   if (!data || !cuts_all || !uniq_all || !sig_all || !st || cap_chunks == 0 || cap_chunks > 0x7FFFFFFFull) return HMSE_EINVAL;
-  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st);
+  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st,
+                                                                                     MhMemo{nullptr, nullptr, MH_MEMO_BITS, 0, 0}, 0);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

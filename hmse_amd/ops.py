@@ -151,8 +151,10 @@ def l4_lsh_update(sig_all: torch.Tensor, n_old: int, n_new: int, cfg: IngestConf
     _check(rc, "hmse_l4_lsh_update")
 
 
-def l4_minhash(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None) -> torch.Tensor:
-    """MinHash signatures -> int32 [n_sel, 128] (uint32 bits). README.md:2578-2598."""
+def l4_minhash(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
+               memo: bool = True) -> torch.Tensor:
+    """MinHash signatures -> int32 [n_sel, 128] (uint32 bits). README.md:2578-2598.
+    memo=False hands the C-ABI a workspace too small for its memo table (include/hmse.h): every hash is then computed."""
     _require_gpu(data, "data")
     _require_gpu(cuts, "cuts")
     if chunk_ids is not None:
@@ -162,7 +164,7 @@ def l4_minhash(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     if n_sel <= 0:
         return sig
     c = cfg.to_c()
-    ws = _ws(256, data.device)
+    ws = _ws(workspace_bytes(STAGE_MINHASH, n_sel, cfg) if memo else 256, data.device)
     rc = _lib.hip_lib().hmse_l4_minhash(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), n_sel, C.byref(c), _ptr(sig),
                                         ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_l4_minhash")

@@ -157,6 +157,10 @@ int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, uint64_t n_
  * MurmurHash3_x86_32(shingle, 4, seed_base + h).
  *   chunk_ids DEVICE u64[n_sel]: chunks to sign (indices into cuts), or NULL = all
  *   sig       DEVICE u32[n_sel][n_hashes]
+ *   ws        hmse_workspace_bytes(HMSE_STAGE_L4_MINHASH, n_sel, cfg) bytes hold the call's memo table (per shingle: which
+ *             of its 128 hashes are small enough to matter; cleared at the start of every call, so a call depends on
+ *             nothing but its arguments).  With a smaller workspace (>= 0 bytes) every hash is computed; the signatures
+ *             are the same either way.
  */
 int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const uint64_t* chunk_ids, uint64_t n_sel, const hmse_cfg* cfg,

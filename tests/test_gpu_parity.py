@@ -132,6 +132,33 @@ def test_l4_minhash_edges_and_selection(orc, dev):
     assert (want[1] == 0xFFFFFFFF).all() and (want[4] == 0xFFFFFFFF).all()  # len < 4 (README.md:2585 underflow guard)
 
 
+def test_l4_minhash_memo_table_changes_nothing(orc, dev):
+    """The memo table of hmse_l4_minhash (which seeds of a shingle hash below 2^22, looked up instead of recomputed) is an
+    optimisation only: with and without it the signatures are identical — on text (warm table: launches of growing size, ~7 k
+    chunks), on random bytes (no repeating 4-grams: the table fills up, wavefronts stop looking), on tiny chunks (most
+    seeds end above the threshold and are re-evaluated), on chunks above 12 KiB (two passes) — and equal the oracle's."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ops
+    cfg = IngestConfig()
+    rng = np.random.default_rng(3)
+    text = corpus.wiki_synth(64 << 20, seed=42)
+    for name, data in (("text", text), ("random", rng.integers(0, 256, 24 << 20, dtype=np.uint8))):
+        d = to_dev(data, dev)
+        cuts = ops.l2_cdc(d, cfg)
+        a = ops.l4_minhash(d, cuts, cfg)
+        b = ops.l4_minhash(d, cuts, cfg, memo=False)
+        assert torch.equal(a, b), name
+        k = 40
+        want = orc.minhash_chunks(data, cuts.cpu().numpy().astype(np.uint64), ocfg(orc, cfg), np.arange(cuts.numel() - 1 - k, cuts.numel() - 1, dtype=np.uint64))
+        assert np.array_equal(a[-k:].cpu().numpy().view(np.uint32), want), name      # the last chunks: the warmest table
+    # fixed tiny / large chunks over the same text
+    for size in (64, 300, 2048, 20000, 32768):
+        n = (8 << 20) // size * size
+        cuts = torch.arange(0, n + 1, size, dtype=torch.int64, device=dev)
+        d = to_dev(text[:n], dev)
+        assert torch.equal(ops.l4_minhash(d, cuts, cfg), ops.l4_minhash(d, cuts, cfg, memo=False)), size
+
+
 def test_l4_lsh_bit_exact(orc, dev):
     from hmse_amd import IngestConfig, ops
     cfg = IngestConfig()
