@@ -25,10 +25,10 @@ constexpr int MH_DEFAULT_VARIANT = 5;
 // 270 G gathers/s while the table stays L2-resident, tools/ubench/gmem_gather.hip) and run the tail loop only over the
 // misses.  EXACT: a seed whose minimum over the looked-up and the computed shingles is below TAU has its true minimum
 // (every hash below TAU is in the table or was computed); the few seeds that end at or above TAU (0.02 % for a chunk of
-// 4.4 k shingles, 2 % for one of 2 k; with TAU = 2^22 this re-evaluation was a quarter of the kernel) are re-evaluated over all distinct shingles of the chunk.  The table is read-only inside a launch as
-// far as correctness goes (a stale or missing entry is a miss); hmse_l4_minhash clears it per call and issues launches
-// of growing size, so that all but the first few hundred chunks meet a warm table whatever the caches of the other XCDs
-// hold.  Capacity 2^18 slots (2 MiB: the table has to stay L2-resident beside the streaming corpus — 2^17: 24.5 ms, 2^18: 21.7,
+// 4.4 k shingles, 2 % for one of 2 k; with TAU = 2^22 this re-evaluation was a quarter of the kernel) are re-evaluated over all distinct shingles of the chunk.  A stale or missing entry is a miss, so nothing depends on when another
+// XCD's L2 shows an insert (measured inside ONE cold launch: 95 % of the lookups hit; whether the table has filled up
+// is asked once per pass with an L2-bypassing load, because every insert costs two ballots and a global CAS).
+// hmse_l4_minhash clears the table per call.  Capacity 2^18 slots (2 MiB: the table has to stay L2-resident beside the streaming corpus — 2^17: 24.5 ms, 2^18: 21.7,
 // 2^19: 28.4, 2^20: 27.3 ms per 2 GiB), filled to one half with the first 131 k distinct shingles met (the frequent ones
 // come early), then no more inserts: data without repeating 4-grams (random
 // bytes) costs what it cost before plus the lookups of the first MH_SAMPLE shingles per wavefront, after which the
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[MH_SLOTS];
   __shared__ uint32_t s_sig[NT / 64][128];
   __shared__ uint32_t s_min[128], s_pass[128], s_glob[128], s_unres[128];
-  __shared__ uint32_t s_flag, s_nun, s_any;
+  __shared__ uint32_t s_flag, s_nun, s_any, s_ins;
   if (st) { chunk_ids += st[SB_U_OLD]; sig += 128 * st[SB_U_OLD]; n_sel = st[SB_U_NEW]; }   // captured chain: this batch's stored chunks
   const uint64_t sel = sel0 + blockIdx.x;
   if (sel >= n_sel) return;
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
   const uint32_t sr0 = rotl32(seed_base + lane, 13), sr1 = rotl32(seed_base + lane + 64, 13);
   constexpr int PART = MH_SLOTS / (NT / 64);  // each wavefront compacts and streams its own part of the table
   uint32_t* q = s_tab + w * PART;
-  const bool ins = memo.tab && *memo.count < memo.cap;   // room for new entries (read once: the count only grows)
   if (t < 128) { s_glob[t] = 0xFFFFFFFFu; s_min[t] = 0xFFFFFFFFu; }
   if (t == 0) { s_nun = 0; s_any = 0; }
 
@@ -111,8 +110,14 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
     const uint32_t cnt = (uint32_t)((nsh - sub0) < (uint64_t)MH_SUB ? (nsh - sub0) : (uint64_t)MH_SUB);
     // clear the set
     for (uint32_t i = t; i < MH_SLOTS / 4; i += NT) ((uint4*)s_tab)[i] = make_uint4(MH_EMPTY, MH_EMPTY, MH_EMPTY, MH_EMPTY);
-    if (t == 0) s_flag = 0;
+    if (t == 0) {
+      s_flag = 0;
+      // room for new entries?  Asked once per pass with a load that bypasses this XCD's L2: in a launch that starts cold, the
+      // workgroups that start later must see that the table has filled up (every insert is two ballots and a global CAS)
+      s_ins = memo.tab && __hip_atomic_load(memo.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < memo.cap;
+    }
     __syncthreads();
+    const bool ins = s_ins != 0;
     // insert R of every shingle of this pass
     const uint8_t* src = data + start + sub0;
     for (uint32_t p = t; p < (V == 3 ? 0u : cnt); p += NT) {
@@ -331,14 +336,7 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
     default: break;
   }
 #endif
-  // launches of growing size: the first chunks fill the table, all later launches start from a warm one
-  uint64_t done = 0, step = memo.tab ? 256 : n_sel;
-  while (done < n_sel) {
-    const uint64_t cnt = (n_sel - done) < step ? (n_sel - done) : step;
-    l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cnt), dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, memo, done);
-    done += cnt;
-    step = step >= (1u << 18) ? n_sel : step * 4;
-  }
+  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)n_sel), dim3(1024), 0, stream>>>(data, n, cuts, chunk_ids, n_sel, cfg->seed_base, sig, nullptr, memo, 0);
   PROF_END(HMSE_STAGE_L4_MINHASH, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
@@ -346,10 +344,16 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
 
 // captured chain: one workgroup per POSSIBLE stored chunk of the batch; those beyond the device-side count leave at once
 int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
-                        const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, hipStream_t stream) {
+                        const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!data || !cuts_all || !uniq_all || !sig_all || !st || cap_chunks == 0 || cap_chunks > 0x7FFFFFFFull) return HMSE_EINVAL;
-  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st,
-                                                                                     MhMemo{nullptr, nullptr, MH_MEMO_BITS, 0, 0}, 0);
+  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, 1u << (MH_MEMO_BITS - 1), 0};
+  if (ws && ws_bytes >= hmse_l4_minhash_workspace_bytes_impl(cap_chunks)) {   // the batch's memo table (cleared per batch: two memset nodes)
+    memo.count = (uint32_t*)ws;
+    memo.tab = (unsigned long long*)((uint8_t*)ws + 256);
+    HMSE_HIP(hipMemsetAsync(ws, 0, 256, stream));
+    HMSE_HIP(hipMemsetAsync(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream));
+  }
+  l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st, memo, 0);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

@@ -92,7 +92,7 @@ __global__ void advance_kernel(uint64_t* st, uint64_t batch_bytes) {
 struct Ws {
   uint64_t* cuts_local; uint64_t* n_cuts; uint32_t* l2_status; uint64_t* sel_ids; int64_t* sel_base; uint64_t* n_sel;
   uint64_t* out_off; uint8_t* kind; uint32_t* dfl_status;
-  uint8_t* l2_ws; size_t l2_bytes; uint8_t* sha_ws; size_t sha_bytes; uint8_t* dfl_ws; size_t dfl_bytes;
+  uint8_t* l2_ws; size_t l2_bytes; uint8_t* sha_ws; size_t sha_bytes; uint8_t* mh_ws; size_t mh_bytes; uint8_t* dfl_ws; size_t dfl_bytes;
   size_t total;
 };
 
@@ -100,6 +100,7 @@ struct Ws {
 
 size_t hmse_l2_workspace_bytes_impl(uint64_t n, uint32_t n_seg, const hmse_cfg* cfg);
 size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t n_chunks);
+size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
 
 static uint64_t sb_cap_chunks(uint64_t batch_bytes, uint32_t n_seg, const hmse_cfg* cfg) { return batch_bytes / cfg->min_size + n_seg + 2; }
@@ -121,6 +122,8 @@ static sb::Ws sb_carve(void* ws, uint64_t batch_bytes, uint32_t n_seg, const hms
   r.l2_ws = w.take<uint8_t>(r.l2_bytes);
   r.sha_bytes = hmse_l3_sha256_workspace_bytes_impl(cap);
   r.sha_ws = w.take<uint8_t>(r.sha_bytes);
+  r.mh_bytes = hmse_l4_minhash_workspace_bytes_impl(cap);
+  r.mh_ws = w.take<uint8_t>(r.mh_bytes);
   // DEFLATE: fixed part + the record area for the worst case (every chunk stored, every one with a dictionary)
   r.dfl_bytes = hmse_l1_deflate_workspace_bytes_impl(cap, cfg) + 2 * (5 * batch_bytes + 1600 * cap) + 4096;
   r.dfl_ws = w.take<uint8_t>(r.dfl_bytes);
@@ -161,7 +164,7 @@ extern "C" int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batc
   if ((rc = hmse_l3_index_update_dyn(digests_all, first_occ, refcount, l3_table, l3_slots, state, cap, stream)) != HMSE_OK) return rc;
   sb::select_uniq_kernel<<<dim3(1), dim3(1024), 0, stream>>>(first_occ, uniq_all, state, max_unique);
   // L4: signatures of the new stored chunks, persistent band tables
-  if ((rc = hmse_l4_minhash_dyn(data, data_cap, cuts_all, uniq_all, sig_all, state, cap, cfg, stream)) != HMSE_OK) return rc;
+  if ((rc = hmse_l4_minhash_dyn(data, data_cap, cuts_all, uniq_all, sig_all, state, cap, cfg, w.mh_ws, w.mh_bytes, stream)) != HMSE_OK) return rc;
   if ((rc = hmse_l4_lsh_update_dyn(sig_all, band_keys, base_all, lsh_tables, lsh_slots, state, cap, cfg, stream)) != HMSE_OK) return rc;
   // L1: dictionary DEFLATE of the new stored chunks (a dictionary may be any stored chunk of the stream so far)
   sb::prep_deflate_kernel<<<dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, stream>>>(uniq_all, base_all, state, w.sel_ids, w.sel_base, w.n_sel);
