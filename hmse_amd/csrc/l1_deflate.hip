@@ -497,13 +497,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // order, so bucket contents are already ordered between steps; inside one step the same-hash
       // positions land in the contiguous slot range [before, after) of their bucket in arbitrary order
       // and are ranked there (a handful of entries: the quadratic rank is over the step's duplicates
-      // only, not over the whole bucket).  Three barriers per step.
+      // only, not over the whole bucket).  Two barriers per step: the next step's read of the cursors (which needs this
+      // step's increments, complete at the first barrier) sits in front of the second one, so that barrier also separates
+      // it from the next step's increments; the in-place rewrite of this step's slots [before, after) then runs beside the
+      // next step's scatter into slots >= after.
+      uint32_t q = t, h = 0, before = 0;
+      bool act = q < nh;
+      if (act) { h = hash4(ld32(W + q)); before = cur_get(cur, h); }
+      __syncthreads();
       for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
-        const uint32_t q = q0 + t;
-        const bool act = q < nh;
-        uint32_t h = 0, before = 0;
-        if (act) { h = hash4(ld32(W + q)); before = cur_get(cur, h); }
-        __syncthreads();
         if (act) S[cur_inc(cur, h)] = (uint16_t)q;
         __syncthreads();
         uint32_t r = 0;
@@ -511,8 +513,13 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           const uint32_t after = cur_get(cur, h);
           for (uint32_t jj = before; jj < after; jj++) r += S[jj] < q;
         }
+        const uint32_t qn = q0 + NT + t;
+        const bool actn = qn < nh;
+        uint32_t hn = 0, beforen = 0;
+        if (actn) { hn = hash4(ld32(W + qn)); beforen = cur_get(cur, hn); }
         __syncthreads();
         if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = W[q + 4]; }
+        q = qn; act = actn; h = hn; before = beforen;
       }
       __syncthreads();  // cursor h now = end of bucket h
     }
