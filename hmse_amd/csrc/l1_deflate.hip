@@ -461,8 +461,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     if (t < 32) sm.df[t] = 0;
     if (t < 20) sm.cf[t] = 0;
     if (t == 0) sm.qhead = 0;
-    for (uint32_t i = t; i < L; i += NT) mlen[i] = 0;
-    if (variant) for (uint32_t i = t; i < L; i += NT) mlenF[i] = 0;
+    // (16 bytes per store: both arrays start on a 16-byte boundary and hold LCAP = a multiple of 16 bytes)
+    for (uint32_t i = t * 16; i < L; i += NT * 16) *(uint4*)(mlen + i) = make_uint4(0, 0, 0, 0);
+    if (variant) for (uint32_t i = t * 16; i < L; i += NT * 16) *(uint4*)(mlenF + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     STAMP(0);

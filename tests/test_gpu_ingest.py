@@ -260,7 +260,8 @@ def test_global_l4_three_shards_equal_the_one_shard_run(dev):
 
 def test_distributed_ingest_world_size_1_runs_rccl(dev):
     """ingest_shard(distributed=True) under the driver: RCCL init, the count and digest all-gathers and the gathered dedupe
-    run at world size 1 and give the single-shard result (the N > 1 exchange itself is covered by the gloo tests)."""
+    run at world size 1 and give the single-shard result (the N > 1 exchange itself is covered by the gloo tests); with
+    global_l4 also the signature all-gather and the base-fetch all-to-alls."""
     import os
     import torch
     import torch.distributed as dist
@@ -276,8 +277,10 @@ def test_distributed_ingest_world_size_1_runs_rccl(dev):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         res = ingest.ingest_shard(data, cfg, distributed=True)
+        glob = ingest.ingest_shard(data, cfg, distributed=True, global_l4=True)   # + signature all-gather and the three all-to-alls (empty at world size 1)
     finally:
         dist.destroy_process_group()
+    assert torch.equal(glob.streams, ref.streams) and torch.equal(glob.base_global, ref.base) and torch.equal(glob.base, ref.base)
     assert res.shard_bases == [0] and res.chunk_base == 0 and res.n_global == ref.cuts.numel() - 1
     for a, b in ((res.first_occ, ref.first_occ), (res.uniq_ids, ref.uniq_ids), (res.base, ref.base), (res.streams, ref.streams), (res.kind, ref.kind)):
         assert torch.equal(a, b)
