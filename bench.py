@@ -285,9 +285,9 @@ def main():
     # read path, outside the timed region: every stored record is inflated on the GPU and its SHA-256
     # re-checked; on one GPU the whole corpus is also reassembled (pointers included) and compared byte for byte
     read_info = None
-    remote_dicts = a.global_l4 and distributed   # records may then name dictionaries stored on other ranks: no per-rank read-back/manifest
+    remote_dicts = a.global_l4 and distributed   # records may then name dictionaries stored on other ranks: no per-rank read-back
     if remote_dicts:
-        read_info = {"scope": "skipped: with --global-l4 a record's dictionary may be stored on another rank (read.reconstruct_shards decodes all shards together)"}
+        read_info = {"scope": "skipped: with --global-l4 a record's dictionary may be stored on another rank (read.read_store decodes the merged store, read.reconstruct_shards the shard results)"}
     elif res.streams is not None and res.digests is not None and os.environ.get("HMSE_BENCH_NO_VERIFY") != "1":
         from hmse_amd import read
         for s in (16, 17):
@@ -317,7 +317,7 @@ def main():
 
     # the product's output: the shard's manifest records, packed on the GPU (outside the timed region, reported beside it)
     manifest_info = None
-    if res.streams is not None and os.environ.get("HMSE_BENCH_NO_MANIFEST") != "1" and not remote_dicts:
+    if res.streams is not None and os.environ.get("HMSE_BENCH_NO_MANIFEST") != "1":
         from hmse_amd import manifest
         sb = res.shard_bases
         manifest.pack_manifest_device(res, rank, world if sb else 1)   # warm-up (allocator, first launch)

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void records_kernel(Args a) {
       const int64_t b = a.base[k];
       uint32_t blba = 0xFFFFFFFFu, blen = 0;
       if (b >= 0 && (uint64_t)b < k) { blba = (uint32_t)(a.rec_off[b] / a.lba_unit); blen = rec_len_of(a, (uint64_t)b); }
+      else if (b == -2) { }               // dictionary stored on ANOTHER shard (global L4): header left unresolved (lba 0xFFFFFFFF,
+                                          // length 0) and filled in by the store merge from that shard's index, like a cross-shard POINTER
       else atomicOr(a.status, 2u);        // a DELTA record needs an EARLIER stored chunk as dictionary
       const uint32_t w0 = blba, w1 = (blen & 0xFFFFu) | (slen << 16);
       __builtin_memcpy(dst, &w0, 4); __builtin_memcpy(dst + 4, &w1, 4);

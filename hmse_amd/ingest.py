@@ -39,6 +39,7 @@ class ShardResult:
     shard_bases: list | None = None    # sharded runs: chunk_base of every shard (what the manifest needs to name a target shard)
     base_global: torch.Tensor | None = None   # global L4: int64 [u] GLOBAL stored-chunk index of the dictionary, -1 none
     u_base: int = 0                    # global L4: global stored-chunk index of this shard's first stored chunk
+    u_bases: list | None = None        # global L4: u_base of every shard
 
 
 def fixed_cuts(n: int, cfg: IngestConfig, seg_off: torch.Tensor) -> torch.Tensor:
@@ -206,7 +207,7 @@ def ingest_shard(data: torch.Tensor, cfg: IngestConfig, seg_off: torch.Tensor | 
     del data_x
     res = ShardResult(n, cuts, digests, chunk_base, n_global, first_occ, refcount, uniq_ids, sig, band_keys, base,
                       streams, stream_off, kind, shard_bases=shard_bases)
-    res.base_global, res.u_base = base_global, u_base
+    res.base_global, res.u_base, res.u_bases = base_global, u_base, u_bases
     if want_stats:
         res.stats = shard_stats(res)
     return res

@@ -26,6 +26,7 @@ MAGIC = b"HMSEMI35"
 CHUNK_INDEX_DTYPE = np.dtype([("sha256", "u1", 32), ("lba", "<u4"), ("length", "<u2"), ("refcount", "<u2")])
 DELTA_HDR_DTYPE = np.dtype([("base_lba", "<u4"), ("base_length", "<u2"), ("delta_length", "<u2")])
 POINTER_DTYPE = np.dtype([("target_lba", "<u4"), ("target_length", "<u2"), ("flags", "<u2")])
+REMOTE_BASE_DTYPE = np.dtype([("slot", "<u4"), ("shard", "<u4"), ("base_slot", "<u4")])   # DELTA record `slot` of this shard: dictionary = record `base_slot` of `shard`
 MAP_DTYPE = np.dtype([("slot", "<u4"), ("raw_length", "<u2"), ("kind", "u1"), ("shard", "u1")])
 assert CHUNK_INDEX_DTYPE.itemsize == 40 and DELTA_HDR_DTYPE.itemsize == 8 and POINTER_DTYPE.itemsize == 8
 
@@ -41,23 +42,35 @@ class Manifest:
     shard: int = 0
     n_shards: int = 1
     chunk_base: int = 0    # global index of this shard's chunk 0
+    remote_bases: np.ndarray | None = None   # REMOTE_BASE_DTYPE: DELTA records whose dictionary is another shard's record (global L4)
+
+    def n_remote(self) -> int:
+        return 0 if self.remote_bases is None else len(self.remote_bases)
 
     def to_bytes(self) -> bytes:
-        hdr = MAGIC + struct.pack("<IIQQQQIIQ", 2, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size,
+        # version 2 = no record names a dictionary outside its own blob; version 3 appends the table of those that do
+        # (the 8-byte DeltaChunk header of README.md:2182-2189 has no room for a shard number)
+        nr = self.n_remote()
+        hdr = MAGIC + struct.pack("<IIQQQQIIQ", 3 if nr else 2, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size,
                                   self.shard, self.n_shards, self.chunk_base)
-        return hdr + self.index.tobytes() + self.chunk_map.tobytes() + self.pointers.tobytes() + self.blob.tobytes()
+        tail = struct.pack("<Q", nr) + self.remote_bases.tobytes() if nr else b""
+        return hdr + self.index.tobytes() + self.chunk_map.tobytes() + self.pointers.tobytes() + self.blob.tobytes() + tail
 
     @staticmethod
     def from_bytes(b: bytes) -> "Manifest":
         assert b[:8] == MAGIC
         ver, unit, nu, nc, npt, nb, shard, n_shards, cbase = struct.unpack_from("<IIQQQQIIQ", b, 8)
-        assert ver == 2
+        assert ver in (2, 3)
         o = 8 + struct.calcsize("<IIQQQQIIQ")
         idx = np.frombuffer(b, CHUNK_INDEX_DTYPE, nu, o); o += nu * 40
         cmap = np.frombuffer(b, MAP_DTYPE, nc, o); o += nc * 8
         ptr = np.frombuffer(b, POINTER_DTYPE, npt, o); o += npt * 8
-        blob = np.frombuffer(b, np.uint8, nb, o)
-        return Manifest(unit, idx, cmap, ptr, blob, shard, n_shards, cbase)
+        blob = np.frombuffer(b, np.uint8, nb, o); o += nb
+        remote = None
+        if ver == 3:
+            (nr,) = struct.unpack_from("<Q", b, o)
+            remote = np.frombuffer(b, REMOTE_BASE_DTYPE, nr, o + 8)
+        return Manifest(unit, idx, cmap, ptr, blob, shard, n_shards, cbase, remote)
 
     def nbytes(self) -> int:
         return 8 + struct.calcsize("<IIQQQQIIQ") + self.index.nbytes + self.chunk_map.nbytes + self.pointers.nbytes + self.blob.nbytes
@@ -77,10 +90,6 @@ def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
         raise ops.HmseError(-1, "the manifest is packed on the GPU: the ShardResult must live in HBM")
     if res.streams is None:
         raise ops.HmseError(-1, "the manifest needs the L1 layer's streams")
-    if getattr(res, "base_global", None) is not None and bool(((res.base_global >= 0) & (res.base < 0)).any()):
-        # the 8-byte DeltaChunk header (README.md:2182-2189) names its base by an LBA of the SAME blob: a record whose
-        # dictionary lives on another shard has no on-disk form yet (ingest_shard(global_l4=True) is an ingest-side feature)
-        raise ops.HmseError(-1, "records with dictionaries on other shards cannot be packed into a per-shard manifest")
     dev = res.cuts.device
     n = res.cuts.numel() - 1
     u = res.uniq_ids.numel()
@@ -104,6 +113,25 @@ def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
     return unit, blob, index, cmap, ptrs
 
 
+def remote_base_table(res) -> np.ndarray | None:
+    """DELTA records of a global-L4 shard whose dictionary is stored on another shard: (slot, shard, that shard's slot).
+    Their DeltaChunk headers are packed unresolved (base_lba 0xFFFFFFFF); merge_manifests() fills them in."""
+    import torch
+    bg = getattr(res, "base_global", None)
+    if bg is None:
+        return None
+    remote = (bg >= 0) & (res.base < 0) & (res.kind == KIND_DELTA)
+    slots = remote.nonzero().flatten()
+    if slots.numel() == 0:
+        return None
+    ub = torch.as_tensor(list(res.u_bases), dtype=torch.int64, device=bg.device)
+    g = bg[slots]
+    sh = torch.searchsorted(ub, g, right=True) - 1
+    out = np.zeros(slots.numel(), REMOTE_BASE_DTYPE)
+    out["slot"] = slots.cpu().numpy(); out["shard"] = sh.cpu().numpy(); out["base_slot"] = (g - ub[sh]).cpu().numpy()
+    return out
+
+
 def build_manifest(res, shard: int = 0, n_shards: int = 1) -> Manifest:
     """pack_manifest_device() + one device -> host copy per array: the host receives four finished arrays and only has to
     write() them.  A chunk whose first occurrence lives on another shard (sharded ingest) becomes a POINTER
@@ -111,7 +139,7 @@ def build_manifest(res, shard: int = 0, n_shards: int = 1) -> Manifest:
     unit, blob, index, cmap, ptrs = pack_manifest_device(res, shard, n_shards)
     host = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)
     return Manifest(unit, host(index, CHUNK_INDEX_DTYPE), host(cmap, MAP_DTYPE), host(ptrs, POINTER_DTYPE), blob.cpu().numpy(),
-                    shard, n_shards, int(res.chunk_base))
+                    shard, n_shards, int(res.chunk_base), remote_base_table(res))
 
 
 @dataclass
@@ -159,7 +187,22 @@ def merge_manifests(parts: list) -> Store:
             ptrs["target_lba"][rec] = t.index["lba"][slot]
             ptrs["target_length"][rec] = t.index["length"][slot]
             ptrs["flags"][rec] = KIND_POINTER | (int(r) << 4)
-        out.append(Manifest(m.lba_unit, m.index, cmap, ptrs, m.blob, m.shard, m.n_shards, m.chunk_base))
+        blob = m.blob
+        if m.n_remote():
+            # DeltaChunk headers whose dictionary lives in an earlier shard's blob: {base_lba, base_length} from that shard's index
+            # (which shard: the manifest's remote_bases table — the 8-byte header has no room for it)
+            blob = m.blob.copy()
+            rb = m.remote_bases
+            assert (rb["shard"] < m.shard).all(), "a dictionary is always an EARLIER stored chunk"
+            for r in np.unique(rb["shard"]):
+                t = parts[int(r)]
+                sel = rb[rb["shard"] == r]
+                pos = m.index["lba"][sel["slot"]].astype(np.int64) * m.lba_unit
+                h = np.zeros(len(sel), DELTA_HDR_DTYPE)
+                h["base_lba"] = t.index["lba"][sel["base_slot"]]; h["base_length"] = t.index["length"][sel["base_slot"]]
+                h["delta_length"] = m.index["length"][sel["slot"]] - 8
+                blob[pos[:, None] + np.arange(8)[None, :]] = np.frombuffer(h.tobytes(), np.uint8).reshape(len(sel), 8)
+        out.append(Manifest(m.lba_unit, m.index, cmap, ptrs, blob, m.shard, m.n_shards, m.chunk_base, m.remote_bases))
     return Store(out)
 
 
@@ -176,6 +219,7 @@ def reconstruct(m) -> bytes:
         own = s.chunk_map["kind"] != KIND_POINTER
         k[s.chunk_map["slot"][own]] = s.chunk_map["kind"][own]
         slot_kind.append(k)
+    remote = [{int(e["slot"]): (int(e["shard"]), int(e["base_slot"])) for e in (s.remote_bases if s.remote_bases is not None else [])} for s in shards]
     cache: dict[tuple[int, int], bytes] = {}
 
     def raw_of(r: int, slot: int) -> bytes:
@@ -187,7 +231,10 @@ def reconstruct(m) -> bytes:
         rec = s.blob[o:o + int(e["length"])].tobytes()
         if slot_kind[r][slot] == KIND_DELTA:  # DeltaChunk record: 8-byte header, then a stream with the base as dictionary
             base_lba, base_len, dlen = struct.unpack_from("<IHH", rec, 0)
-            d = zlib.decompressobj(-15, zdict=raw_of(r, by_lba[r][base_lba]))
+            br, bslot = remote[r][slot] if slot in remote[r] else (r, by_lba[r][base_lba])   # the dictionary may be another shard's record
+            if br != r and (base_lba == 0xFFFFFFFF or int(shards[br].index["lba"][bslot]) != base_lba):
+                raise ValueError("a cross-shard DeltaChunk header is unresolved: merge_manifests() the shards first")
+            d = zlib.decompressobj(-15, zdict=raw_of(br, bslot))
             out = d.decompress(rec[8:8 + dlen]) + d.flush()
         else:
             d = zlib.decompressobj(-15)

@@ -305,6 +305,8 @@ def manifest_pack(res, shard: int, n_shards: int, shard_bases, rec_off: torch.Te
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = _ws(workspace_bytes(STAGE_MANIFEST, n, IngestConfig()), dev)
     base = res.base if res.base is not None else torch.full((res.uniq_ids.numel(),), -1, dtype=torch.int64, device=dev)
+    if getattr(res, "base_global", None) is not None:   # dictionaries stored on other shards: -2 (an unresolved DeltaChunk header)
+        base = torch.where((res.base_global >= 0) & (base < 0), torch.full_like(base, -2), base)
     sb = None
     if n_shards > 1:
         sb = torch.as_tensor(list(shard_bases), dtype=torch.int64, device=dev)

@@ -114,37 +114,59 @@ def parse_manifest(m: Manifest) -> dict:
     s_off = rec_off + np.where(is_delta, 8, 0)
     s_len = idx["length"].astype(np.int64) - np.where(is_delta, 8, 0)
     base = np.full(u, -1, np.int64)
+    base_shard = np.full(u, m.shard, np.int64)          # which shard's slot `base` names (global L4: possibly an earlier shard's)
     if is_delta.any():
         # DeltaChunk header {base_lba u32, base_length u16, delta_length u16} (README.md:2182-2189)
         hdr_pos = rec_off[is_delta][:, None] + np.arange(8)[None, :]
         hdr = m.blob[hdr_pos].copy().view("<u4")  # [:,0] base_lba, [:,1] lengths
-        order = np.argsort(idx["lba"], kind="stable")
-        pos = np.searchsorted(idx["lba"][order], hdr[:, 0])
-        if (pos >= u).any() or (idx["lba"][order][np.minimum(pos, u - 1)] != hdr[:, 0]).any():
-            raise ReadError("a DeltaChunk header names an LBA that is not in the index")
-        base[is_delta] = order[pos]
         s_len[is_delta] = hdr[:, 1] >> 16
-    return {"kind": slot_kind, "base": base, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
+        local = np.ones(u, bool)
+        if m.n_remote():                                 # dictionaries in another shard's blob: named by the manifest's table
+            rb = m.remote_bases
+            local[rb["slot"]] = False
+            base[rb["slot"]] = rb["base_slot"]; base_shard[rb["slot"]] = rb["shard"]
+        loc = local[is_delta]
+        order = np.argsort(idx["lba"], kind="stable")
+        pos = np.searchsorted(idx["lba"][order], hdr[loc, 0])
+        if (pos >= u).any() or (idx["lba"][order][np.minimum(pos, u - 1)] != hdr[loc, 0]).any():
+            raise ReadError("a DeltaChunk header names an LBA that is not in the index")
+        base[np.nonzero(is_delta)[0][loc]] = order[pos]
+    return {"kind": slot_kind, "base": base, "base_shard": base_shard, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
 
 
 def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
     """A sharded store (one Manifest per shard, cross-shard pointers resolved by manifest.merge_manifests) -> the
-    original corpus in global chunk order, decoded on `device`: every shard's records are inflated (a DELTA's dictionary
-    is always a chunk of the same shard), then ONE assembly pass lays out every chunk from the slot its map entry names —
-    its own shard's or, for a cross-shard POINTER, another's (README.md:1635-1669)."""
+    original corpus in global chunk order, decoded on `device`: the records of all shards are inflated in one call, then
+    ONE assembly pass lays out every chunk from the slot its map entry names — its own shard's or, for a cross-shard
+    POINTER, another's (README.md:1635-1669)."""
     from .manifest import PTR_UNRESOLVED
     if any(((m.pointers["flags"] & PTR_UNRESOLVED) != 0).any() for m in store.shards):
         raise ReadError("the store has unresolved cross-shard pointers: merge_manifests() its shards first")
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
-    raws, raw_offs, run = [], [], 0
-    for m in store.shards:
-        p = parse_manifest(m)
-        raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(p["stream_off"], torch.int64), t(p["kind"], torch.uint8), t(p["base"], torch.int64),
-                                         t(p["raw_len"], torch.int64), stream_len=t(p["stream_len"], torch.int32))
-        raws.append(raw); raw_offs.append(raw_off[:-1] + run); run += int(raw.numel())
-    raw_all = torch.cat(raws) if raws else torch.empty(0, dtype=torch.uint8, device=device)
-    raw_off_all = torch.cat(raw_offs + [torch.tensor([run], dtype=torch.int64, device=device)])
+    # ONE inflate call over the records of all shards, in (shard, slot) order: a DELTA's dictionary is an earlier record of
+    # its own shard or — in a store ingested with global L4 — of an earlier shard (manifest.remote_bases)
     sb = np.cumsum([0] + [len(m.index) for m in store.shards])
+    bb = np.cumsum([0] + [int(m.blob.size) for m in store.shards])
+    ps = [parse_manifest(m) for m in store.shards]
+    for m, p in zip(store.shards, ps):
+        if m.n_remote():
+            rb = m.remote_bases
+            lba = m.blob[(m.index["lba"][rb["slot"]].astype(np.int64) * m.lba_unit)[:, None] + np.arange(4)[None, :]].copy().view("<u4")[:, 0]
+            want = np.array([store.shards[int(r)].index["lba"][int(b)] for r, b in zip(rb["shard"], rb["base_slot"])], np.uint32)
+            if not np.array_equal(lba, want):
+                raise ReadError("the store has unresolved cross-shard DeltaChunk headers: merge_manifests() its shards first")
+    cat = lambda key, adj=None: np.concatenate([(p[key] if adj is None else adj(i, p)) for i, p in enumerate(ps)]) if ps else np.zeros(0, np.int64)
+    base_g = cat("base", lambda i, p: np.where(p["base"] >= 0, sb[p["base_shard"]] + p["base"], -1))
+    if len(base_g):
+        blobs = [t(m.blob, torch.uint8) for m in store.shards if m.blob.size]
+        blob_all = blobs[0] if len(blobs) == 1 else torch.cat(blobs) if blobs else torch.zeros(1, dtype=torch.uint8, device=device)
+        del blobs
+        raw_all, raw_off_all, _ = ops.l1_inflate(blob_all,
+                                                 t(cat("stream_off", lambda i, p: p["stream_off"] + bb[i]), torch.int64),
+                                                 t(cat("kind"), torch.uint8), t(base_g, torch.int64), t(cat("raw_len"), torch.int64),
+                                                 stream_len=t(cat("stream_len"), torch.int32))
+    else:
+        raw_all = torch.empty(0, dtype=torch.uint8, device=device); raw_off_all = torch.zeros(1, dtype=torch.int64, device=device)
     slot_g = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in store.shards]) \
         if store.shards else np.zeros(0, np.int64)
     lens = np.concatenate([m.chunk_map["raw_length"].astype(np.int64) for m in store.shards]) if store.shards else np.zeros(0, np.int64)
@@ -162,6 +184,8 @@ def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
     """Manifest bytes (hmse_amd/manifest.py record formats) -> original data, decoded on `device`."""
     idx, cmap = m.index, m.chunk_map
     u, n = len(idx), len(cmap)
+    if m.n_remote():
+        raise ReadError("records of this manifest use dictionaries stored in other shards: read_store() the merged store")
     p = parse_manifest(m)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
     raw, raw_off, _ = ops.l1_inflate(t(m.blob, torch.uint8), t(p["stream_off"], torch.int64), t(p["kind"], torch.uint8), t(p["base"], torch.int64),

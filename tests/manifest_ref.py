@@ -4,7 +4,7 @@ and the way CPU tests obtain a Manifest from oracle outputs.  TEST INFRASTRUCTUR
 import numpy as np
 
 from hmse_amd.config import KIND_DELTA, KIND_POINTER
-from hmse_amd.manifest import CHUNK_INDEX_DTYPE, DELTA_HDR_DTYPE, MAP_DTYPE, POINTER_DTYPE, PTR_UNRESOLVED, Manifest
+from hmse_amd.manifest import CHUNK_INDEX_DTYPE, DELTA_HDR_DTYPE, MAP_DTYPE, POINTER_DTYPE, PTR_UNRESOLVED, REMOTE_BASE_DTYPE, Manifest
 
 
 def build(res, shard: int = 0, n_shards: int = 1) -> Manifest:
@@ -40,9 +40,21 @@ def build(res, shard: int = 0, n_shards: int = 1) -> Manifest:
         dst = np.repeat(rec_off[:-1] + hdr - off[:-1], slen) + np.arange(off[-1])
         blob[dst] = streams[: off[-1]]
     d = np.nonzero(kind_u == KIND_DELTA)[0]
+    # global L4: a DELTA whose dictionary is another shard's record -> unresolved header + an entry of the remote table
+    bg = res.base_global.cpu().numpy() if getattr(res, "base_global", None) is not None else None
+    remote = None
+    if bg is not None:
+        rs = np.nonzero((bg >= 0) & (base < 0) & (kind_u == KIND_DELTA))[0]
+        if len(rs):
+            ub = np.asarray(res.u_bases, np.int64)
+            sh = np.searchsorted(ub, bg[rs], side="right") - 1
+            remote = np.zeros(len(rs), REMOTE_BASE_DTYPE)
+            remote["slot"] = rs; remote["shard"] = sh; remote["base_slot"] = bg[rs] - ub[sh]
     if len(d):
         h = np.zeros(len(d), DELTA_HDR_DTYPE)
-        h["base_lba"] = index["lba"][base[d]]; h["base_length"] = index["length"][base[d]]; h["delta_length"] = slen[d]
+        loc = base[d] >= 0
+        h["base_lba"] = np.where(loc, index["lba"][np.where(loc, base[d], 0)], 0xFFFFFFFF)
+        h["base_length"] = np.where(loc, index["length"][np.where(loc, base[d], 0)], 0); h["delta_length"] = slen[d]
         pos = rec_off[d][:, None] + np.arange(8)[None, :]
         blob[pos] = np.frombuffer(h.tobytes(), np.uint8).reshape(len(d), 8)
     cmap = np.zeros(n, MAP_DTYPE)
@@ -65,4 +77,4 @@ def build(res, shard: int = 0, n_shards: int = 1) -> Manifest:
     ptr["target_lba"] = np.where(pl, index["lba"][np.where(pl, tslot, 0)] if u else 0, 0xFFFFFFFF)
     ptr["target_length"] = np.where(pl, index["length"][np.where(pl, tslot, 0)] if u else 0, 0)
     ptr["flags"] = KIND_POINTER | (tgt_shard[is_ptr] << 4) | np.where(pl, 0, PTR_UNRESOLVED)
-    return Manifest(unit, index, cmap, ptr, blob, shard, n_shards, cb)
+    return Manifest(unit, index, cmap, ptr, blob, shard, n_shards, cb, remote)

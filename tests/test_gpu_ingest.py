@@ -186,7 +186,8 @@ def _to_host(res):
     from hmse_amd import ingest
     c = lambda t: None if t is None else t.cpu()
     return ingest.ShardResult(res.n_bytes, c(res.cuts), c(res.digests), res.chunk_base, res.n_global, c(res.first_occ), c(res.refcount), c(res.uniq_ids),
-                              c(res.sig), c(res.band_keys), c(res.base), c(res.streams), c(res.stream_off), c(res.kind), shard_bases=res.shard_bases)
+                              c(res.sig), c(res.band_keys), c(res.base), c(res.streams), c(res.stream_off), c(res.kind), shard_bases=res.shard_bases,
+                              base_global=c(getattr(res, "base_global", None)), u_base=getattr(res, "u_base", 0), u_bases=getattr(res, "u_bases", None))
 
 
 def test_two_shard_store_on_one_gpu_merges_and_reads_back(orc, dev):
@@ -254,8 +255,22 @@ def test_global_l4_three_shards_equal_the_one_shard_run(dev):
     late = next(r for r in res if bool(((r.base_global >= 0) & (r.base < 0)).any()))
     with pytest.raises(read.ReadError):
         read.reconstruct_shard(late)
-    with pytest.raises(ops.HmseError):
-        manifest.build_manifest(late, 1, 3)
+    # the sharded STORE of such a run: per-shard manifests whose cross-shard DeltaChunk headers are packed unresolved and
+    # listed in the manifest's remote_bases table; the merge fills them from the owning shard's index; the store reads back
+    # on the GPU (one inflate over all shards) and through stock zlib on the host
+    import manifest_ref
+    parts = [manifest.build_manifest(r, i, 3) for i, r in enumerate(res)]
+    for i, (r, m) in enumerate(zip(res, parts)):
+        assert manifest_ref.build(_to_host(r), i, 3).to_bytes() == m.to_bytes()
+    assert sum(m.n_remote() for m in parts) == n_remote_delta and parts[0].n_remote() == 0
+    with pytest.raises(read.ReadError):
+        read.read_store(manifest.Store(parts), dev)                               # unresolved pointers / headers
+    with pytest.raises(read.ReadError):
+        read.read_manifest(next(m for m in parts if m.n_remote()), dev)
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    assert sum(m.n_remote() for m in store.shards) == n_remote_delta
+    assert torch.equal(read.read_store(store, dev, verify=True), d)
+    assert manifest.reconstruct(store) == data.tobytes()
 
 
 def test_distributed_ingest_world_size_1_runs_rccl(dev):
