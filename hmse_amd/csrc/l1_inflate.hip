@@ -856,7 +856,7 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       uint64_t val = (x >> s6) | (s6 ? y << (64u - s6) : 0ull);
       val = sh >= 128 ? 0ull : val;
       const uint32_t adv = fill ? (63u - n) >> 3 : 0u;
-      acc |= fill ? val << n : 0ull;
+      acc |= fill ? val << (n & 63u) : 0ull;      // (n <= 63 wherever `fill` holds; the mask keeps the shift defined elsewhere)
       p += adv; n += adv * 8u; wo += adv;
     }
 #ifdef HMSE_DIAG
