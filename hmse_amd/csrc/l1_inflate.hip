@@ -903,8 +903,11 @@ __global__ __launch_bounds__(64, 2) void l1_inflate_lanes_kernel(Args a) {
       oc += (cnt);                                                                                           \
     } while (0)
     OB_APPEND(pc0, pc1, pn); pn = 0;
-    { const uint64_t lb = litA & 0xFFu; OB_APPEND(lb, 0ull, (litA ? 1u : 0u)); litA = 0; }
-    { const uint64_t lb = lit & 0xFFu; OB_APPEND(lb, 0ull, (lit ? 1u : 0u)); lit = 0; }
+    {   // the trip's literals (slot A's, then the token step's) as one append
+      const uint64_t lb = litA ? (uint64_t)((litA & 0xFFu) | ((lit & 0xFFu) << 8)) : (uint64_t)(lit & 0xFFu);
+      OB_APPEND(lb, 0ull, ((litA ? 1u : 0u) + (lit ? 1u : 0u)));
+      litA = 0; lit = 0;
+    }
 #undef OB_APPEND
     if (fill && wo > 8) {                                               // fewer than 8 bytes left in the window
       const uint64_t q = p + 16 <= a.streams_bytes ? p : a.streams_bytes - 16;   // the host side guarantees >= 16 bytes
