@@ -243,3 +243,44 @@ def test_energy_model_restatement_reproduces_the_documented_figures():
     at = em.scenario(75, be, 1, 5, 0.5, 36)["total_wh"]
     assert abs(at - r["plain"]["total_wh"]) < 1e-9 and 1.0 < be < 1.03
     assert em.breakeven_cf(0.001, 1000, 5, 0.5, 36) == float("inf")
+
+
+def test_store_with_dictionaries_in_other_shards(orc):
+    """Global L4 (SURVEY.md §8e last sentence) on disk, CPU side: the one-shard oracle run split into three shards' records
+    — first occurrences, bases and streams are those of the one-shard run, so some DELTA records name a dictionary stored in
+    an EARLIER shard.  Their DeltaChunk headers are written unresolved and listed in the manifest's remote_bases table
+    (manifest version 3), the merge fills them from the owning shard's index, and the stock-zlib verifier follows them."""
+    import manifest_ref
+    from test_gpu_ingest import oracle_pipeline
+    from hmse_amd import IngestConfig, corpus, ingest, manifest
+    from hmse_amd.config import KIND_DELTA
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(6 << 20, seed=42)
+    _, (one,) = oracle_pipeline(orc, data, cfg)
+    cuts, uniq, base, off, kind = one["cuts"].astype(np.int64), one["uniq"].astype(np.int64), one["base"], one["off"].astype(np.int64), one["kind"]
+    bounds = [0, 2 << 20, 4 << 20, 6 << 20]
+    cb = [int(np.searchsorted(cuts, b)) for b in bounds]                          # chunk index of every shard boundary (segment-aligned)
+    ub = [int(np.searchsorted(uniq, c)) for c in cb]
+    t = torch.from_numpy
+    parts, n_remote = [], 0
+    for r in range(3):
+        c0, c1, u0, u1 = cb[r], cb[r + 1], ub[r], ub[r + 1]
+        bg = base[u0:u1].copy()
+        loc = np.where((bg >= u0) & (bg < u1), bg - u0, -1)
+        n_remote += int(((bg >= 0) & (loc < 0) & (kind[u0:u1] == KIND_DELTA)).sum())
+        res = ingest.ShardResult(bounds[r + 1] - bounds[r], t(cuts[c0:c1 + 1] - bounds[r]), t(one["dg"][c0:c1]), c0, len(cuts) - 1,
+                                 t(one["fo"][c0:c1].astype(np.int64)), t(np.ones(c1 - c0, np.int32)), t(uniq[u0:u1] - c0), None, None, t(loc),
+                                 t(one["out"][off[u0]:off[u1]]), t(off[u0:u1 + 1] - off[u0]), t(kind[u0:u1]), shard_bases=cb[:3],
+                                 base_global=t(bg), u_base=u0, u_bases=ub[:3])
+        parts.append(manifest_ref.build(res, r, 3))
+    assert n_remote >= 3 and sum(m.n_remote() for m in parts) == n_remote and parts[0].n_remote() == 0
+    pr = next(m for m in parts if m.n_remote())
+    assert manifest.Manifest.from_bytes(pr.to_bytes()).n_remote() == pr.n_remote()                      # version 3 round trip
+    with pytest.raises(Exception):
+        manifest.reconstruct(manifest.Store(parts))                               # unresolved pointers / headers
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    m2 = next(m for m in store.shards if m.n_remote())
+    rb = m2.remote_bases
+    hdr = m2.blob[(m2.index["lba"][rb["slot"]].astype(np.int64) * m2.lba_unit)[:, None] + np.arange(4)[None, :]].copy().view("<u4")[:, 0]
+    assert np.array_equal(hdr, np.array([store.shards[int(s)].index["lba"][int(b)] for s, b in zip(rb["shard"], rb["base_slot"])], np.uint32))
+    assert manifest.reconstruct(store) == data.tobytes()
