@@ -339,19 +339,25 @@ __global__ __launch_bounds__(NT, 8) void l1_inflate_kernel(Args a) {
 //     next 15 stream bits, bit-reversed, are compared with all 15 words (v_cmp + v_cndmask each, fully unrolled, static
 //     register indices): the last word not above the bits carries the code's length, the first code of that length and
 //     the offset of its symbols.  One LDS byte read then gives the symbol.
-//   * per-lane tables in LDS, lane-interleaved words (word w of lane l at w*64+l: conflict-free when lanes touch the same
-//     word index): 288 literal/length symbol bytes (bit 8 of a symbol comes from comparing its index with the count of
-//     literals of that length), 32 distance symbols, 320 code-length nibbles, per-length running offsets: 576 B per lane,
-//     36 KiB per wavefront, four wavefronts per CU = 256 streams in flight per CU, 65 536 on the chip;
-//   * a state machine per lane, one micro-step per loop trip: decode a token / copy up to 16 bytes of a match.  Match
-//     sources are loaded one trip before they are stored (two 8-byte loads, the stores sized by overlapping 8/4-byte
-//     pieces), the bit window is refilled from an 8-byte word loaded one trip ahead, so no trip waits on HBM/L2;
-//     a self-overlapping match doubles its copy distance (a multiple of dist) until 16 bytes fit;
+//   * per lane, LDS holds ONLY the 288 sorted literal/length symbol bytes (bit 8 of a symbol comes from comparing its
+//     index with the count of literals of that length), in lane-interleaved words (word w of lane l at w*64+l: a byte
+//     read is conflict-free whatever the indices): 18 KiB per wavefront, EIGHT wavefronts per CU (two per SIMD),
+//     131 072 streams in flight on the chip.  Everything else is in registers, none of it indexed by a lane: the 30
+//     distance symbols and the per-length counts/offsets in packed 64-bit words, the code lengths of a header in a
+//     40-register FIFO (a queue only ever moves by one);
+//   * a state machine per lane, one micro-step per loop trip: a short-code literal (slot A) plus one token, or up to 14
+//     bytes of a match.  All memory operations of a trip sit in ONE cluster at its end (step 5) whose single wait is for
+//     what the previous trip issued: the stream is read 16 bytes at a time into a register window, a match piece is one
+//     16-byte load appended a trip later, output leaves through a 16-byte register buffer as one store per ~12 bytes;
+//     a self-overlapping match doubles its copy distance (a multiple of dist) until the piece fits;
 //   * block headers (code-length code, length decode, table build: ~15 k instructions per lane) would run with one or
 //     two lanes active if each lane did them when it got there.  Lanes that need a header WAIT until 16 of them do (or
-//     nothing else can run), then go through it together;
-//   * a DELTA stream whose base is not decoded yet builds its tables and then polls the base's flag once per trip
-//     (never a spin: the base may be another lane of this very wavefront).
+//     nothing else can run), then go through it together, reading the header from 288 stream bytes staged in the
+//     (not yet needed) symbol area;
+//   * records are pulled in two passes, those without a dictionary first: a DELTA record then finds its base decoded
+//     (in index order it sat right behind it and its lane idled for the base's whole decode).  A base still in flight
+//     (chains of DELTAs, the seam of the passes) is polled every eighth trip, never spun on: it may be another lane of
+//     this very wavefront.
 // Every wait is bounded (symbol budget per stream, poll budget per base, bytes per copy), so every lane reaches DONE.
 namespace ifl {
 
