@@ -135,3 +135,13 @@ def test_torch_ops_are_registered_and_have_no_cpu_path():
         torch.ops.hmse.l2_cdc(x)
     with pytest.raises(ops.HmseError):
         torch.ops.hmse.l3_sha256(x, torch.tensor([0, 5000]))
+
+
+def test_inflate_mode_knob_and_minhash_workspace():
+    """hmse_l1_inflate_mode accepts 0/1/2 only; the MinHash workspace carries the 2 MiB memo table (include/hmse.h)."""
+    from hmse_amd import IngestConfig, _lib, ops
+    lib = _lib.hip_lib()
+    assert lib.hmse_l1_inflate_mode(3) == -1 and lib.hmse_l1_inflate_mode(-1) == -1
+    for m in (1, 2, 0):
+        assert lib.hmse_l1_inflate_mode(m) == 0
+    assert ops.workspace_bytes(ops.STAGE_MINHASH, 1000, IngestConfig()) == 256 + (8 << 18)
