@@ -205,3 +205,39 @@ def test_read_path_refuses_inconsistent_inputs(orc, dev):
     with pytest.raises(ops.HmseError):
         ops.read_assemble(torch.tensor([0, 20, 46], dtype=torch.int64, device=dev), torch.tensor([0, 0], dtype=torch.int64, device=dev),
                           raw_off[:2].contiguous(), raw[:23].contiguous())
+
+
+def test_inflate_many_small_records_auto_dispatch(orc, dev):
+    """60 000 records (more than the 49 152 from which hmse_l1_inflate picks the lane-per-stream decoder by itself): sizes
+    0..3000, zlib levels 0/1/6/9 and strategies mixed, 15 % with an earlier record as dictionary (chains included), 3 %
+    corrupted — bytes and accept/reject decisions equal the oracle's under the automatic choice and under both forced decoders
+    (this module's fixture forces one; the automatic run is made explicitly)."""
+    import zlib
+    from hmse_amd import ops
+    rnd = random.Random(11)
+    text = words_text(1 << 20, seed=5).tobytes()
+    recs, raws = [], []
+    for k in range(60000):
+        n = rnd.choice((0, 1, 5, 40, 300, 1200, 3000)) if rnd.random() < 0.3 else rnd.randrange(3000)
+        o = rnd.randrange(len(text) - 3000)
+        t = text[o:o + n]
+        b = -1
+        if k > 10 and rnd.random() < 0.15:
+            b = rnd.randrange(max(0, k - 200), k)
+            while recs[b][1] == 0 and b > 0:
+                b -= 1
+        lvl, strat = rnd.choice((0, 1, 6, 9)), rnd.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE))
+        zd = raws[b] if b >= 0 and recs[b][1] else None
+        if zd is None:
+            b = -1
+        c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 9, strat, zdict=zd) if zd else zlib.compressobj(lvl, zlib.DEFLATED, -15, 9, strat)
+        s = c.compress(t) + c.flush()
+        if rnd.random() < 0.03:
+            s = mutate(s, rnd)
+        recs.append((s, len(t), b))
+        raws.append(t)
+    ok = run_both(orc, dev, recs)
+    assert 0.9 * len(recs) < ok.sum() < len(recs)
+    ops.l1_inflate_mode(0)
+    ok0 = run_both(orc, dev, recs)
+    assert np.array_equal(ok, ok0)
