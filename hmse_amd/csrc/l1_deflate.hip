@@ -344,6 +344,7 @@ __device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint3
 #ifdef HMSE_DFL_STAMPS
 // diagnostic build only: per-phase shader-clock totals of thread 0, summed over jobs and workgroups
 __device__ unsigned long long g_dfl_stamps[3][16];
+__device__ unsigned long long g_enc_stamps[8];   // encode kernel: clocks of thread 0 per phase (0 load, 1 trees, 2 rle+cl+decide, 3 codes, 4 emit, 5 copy-out), [7] records
 #define STAMP(i) do { if (t == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -975,6 +976,12 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
+#ifdef HMSE_DFL_STAMPS
+  unsigned long long e_acc0 = 0, e_acc1 = 0, e_acc2 = 0, e_acc3 = 0, e_acc4 = 0, e_acc5 = 0, e_n = 0, e_last = clock64();
+#define ESTAMP(v) do { if (t == 0) { const unsigned long long now__ = clock64(); v += now__ - e_last; e_last = now__; } } while (0)
+#else
+#define ESTAMP(v) do { } while (0)
+#endif
   for (;;) {
   __syncthreads();
   if (t == 0) sm.job = atomicAdd(a.counter, 1u);
@@ -1000,6 +1007,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (t < 32) sm.df[t] = r_hist[288 + t];
   if (t < 20) sm.cf[t] = 0;
   __syncthreads();
+  ESTAMP(e_acc0);
   // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
   if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
   if (wave == 1) huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
@@ -1011,6 +1019,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     if (lane == 0) { sm.fixed_bits = fb + xb + 3; sm.extra_bits = xb; }
   }
   __syncthreads();
+  ESTAMP(e_acc1);
   // ---- phase 9: code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) ---------------------------
   if (wave == 0) {
     uint32_t nlit = 286, ndist = 30;
@@ -1066,6 +1075,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     for (uint32_t x = t; x < L; x += NT) slot[5 + x] = lit[x];
     continue;  // next job (this workgroup is persistent)
   }
+  ESTAMP(e_acc2);
   // ---- phase 10: code tables ------------------------------------------------------------------------------
   if (mode == 1) {
     for (uint32_t s = t; s < 288; s += NT) sm.ll[s] = (uint8_t)fixed_len(s);
@@ -1078,6 +1088,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   __syncthreads();
   for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;  // (the image shares LDS with the scratch used above)
   __syncthreads();
+  ESTAMP(e_acc3);
   // ---- phase 11: emit ----------------------------------------------------------------------------------------
   if (wave == 0) {
     if (lane == 0) { put_bits(out, 0, 1, 1); put_bits(out, 1, mode, 2); }
@@ -1153,13 +1164,25 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   const uint32_t end_bits = sm.hdr_bits + total;
   if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
   __syncthreads();
+  ESTAMP(e_acc4);
   const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
   for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned and has 16 bytes of slack (rec_size)
     const uint4 v = *(const uint4*)((const uint8_t*)out + i);
     *(uint4*)(slot + i) = v;
   }
   if (t == 0) len_out[k] = nbytes;
+  ESTAMP(e_acc5);
+#ifdef HMSE_DFL_STAMPS
+  e_n++;
+#endif
   }
+#ifdef HMSE_DFL_STAMPS
+  if (t == 0) {
+    atomicAdd(&g_enc_stamps[0], e_acc0); atomicAdd(&g_enc_stamps[1], e_acc1); atomicAdd(&g_enc_stamps[2], e_acc2); atomicAdd(&g_enc_stamps[3], e_acc3);
+    atomicAdd(&g_enc_stamps[4], e_acc4); atomicAdd(&g_enc_stamps[5], e_acc5); atomicAdd(&g_enc_stamps[7], e_n);
+  }
+#endif
+#undef ESTAMP
 }
 
 // Size classes of the match kernel (window T = dictionary + chunk).  Per-position arrays in LDS:
@@ -1392,6 +1415,11 @@ static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
 }  // namespace dfl
 
 #ifdef HMSE_DFL_STAMPS
+extern "C" int hmse_debug_encode_stamps(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dfl::g_enc_stamps), sizeof(dfl::g_enc_stamps)) != hipSuccess) return HMSE_EHIP;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_enc_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
+  return HMSE_OK;
+}
 extern "C" int hmse_debug_deflate_stamps(unsigned long long* out48, int reset) {
   if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(dfl::g_dfl_stamps), sizeof(dfl::g_dfl_stamps)) != hipSuccess) return HMSE_EHIP;
   if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }

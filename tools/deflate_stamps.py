@@ -27,6 +27,9 @@ lib.hmse_debug_deflate_stamps(buf.ctypes.data, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
 lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
+ebuf = np.zeros(8, dtype=np.uint64)
+lib.hmse_debug_encode_stamps.argtypes = [C.c_void_p, C.c_int]
+lib.hmse_debug_encode_stamps(ebuf.ctypes.data, 0)
 names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse: stitch", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
 lens = (cuts[1:] - cuts[:-1])[uniq]
 hb = base >= 0
@@ -55,3 +58,9 @@ for c, cn in enumerate(["class S (T <= 9216)", "classes S2, SG (T <= 16000)", "c
     print(cn, "total Mclk %.1f" % (tot / 1e6))
     for i, nm in enumerate(names):
         print("   %-18s %6.2f %%" % (nm, 100 * row[i] / tot))
+
+et = ebuf[:6].astype(np.float64)
+if et.sum():
+    print("encode kernel: %d records (both launches, warm-up included), thread 0's clocks per phase:" % int(ebuf[7]))
+    for nm, v in zip(("load histograms", "trees (lit/len, dist, fixed cost)", "rle + code-length tree + decide", "code tables + image clear", "emit", "copy-out"), et):
+        print("   %-34s %6.2f %%   %8.0f clk per record" % (nm, 100 * v / et.sum(), v / max(1, int(ebuf[7]))))
