@@ -193,10 +193,19 @@ def record_bytes(lens: torch.Tensor) -> torch.Tensor:
     return (1296 + 4 * ((lens + 3) & ~3) + lens + 5 + 16 + 255) & ~255
 
 
+DEFLATE_WS_LIMIT = 64 << 30   # bytes of per-job records one hmse_l1_deflate call may hold (l1_deflate splits a larger selection)
+
+
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
-               base: torch.Tensor | None = None, base_is_chunk_id: bool = False, ws: torch.Tensor | None = None):
+               base: torch.Tensor | None = None, base_is_chunk_id: bool = False, ws: torch.Tensor | None = None,
+               ws_limit: int | None = None):
     """Per-chunk raw DEFLATE with the base chunk as dictionary (`base`: index into the selection, or — with
     base_is_chunk_id — a chunk index into `cuts`, e.g. a chunk stored by an earlier batch of a stream).
+
+    The C-ABI call keeps one record per job (histograms, token list sized for the all-literal worst case, stream slot:
+    ~5.2 x the chunk, twice for a chunk with a dictionary) in its workspace.  A selection whose records exceed `ws_limit`
+    bytes (default DEFLATE_WS_LIMIT) is encoded in consecutive pieces that each fit — same streams, same order, a bounded
+    workspace whatever the shard size.
 
     Returns (out uint8[total], out_off int64[n_sel+1], kind uint8[n_sel]). README.md:2374-2378, 2182-2189."""
     if ws is not None:
@@ -219,16 +228,44 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     c = cfg.to_c()
-    nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_sel, C.byref(c)))
-    if ws is None or ws.numel() < nb + need + 4096:   # (`ws`: a caller-held workspace, e.g. the streaming front end's, reused when big enough)
-        ws = _ws(nb + need + 4096, dev)
-    rc = _lib.hip_lib().hmse_l1_deflate_ex(_ptr(data), data.numel(), _ptr(cuts), _ptr(chunk_ids), _ptr(base), n_sel, C.byref(c),
-                                           1 if base_is_chunk_id else 0, _ptr(out), cap, _ptr(out_off), _ptr(kind), _ptr(status),
-                                           ws.data_ptr(), ws.numel(), _stream())
-    _check(rc, "hmse_l1_deflate")
-    total = int(out_off[-1].item())
-    if int(status.item()):
-        raise HmseError(-2, f"hmse_l1_deflate device status {int(status.item()):#x}")
+    limit = DEFLATE_WS_LIMIT if ws_limit is None else int(ws_limit)
+    if need <= limit:
+        pieces = [(0, n_sel, need)]
+        ids_all, base_all, by_id = chunk_ids, base, base_is_chunk_id
+    else:
+        # consecutive pieces of the selection whose records fit; dictionaries are named by chunk id so that a piece may
+        # use a chunk of an earlier piece
+        csum = torch.cumsum(rec * nvar, 0)
+        ends, lo, start = [], 0, 0
+        while start < n_sel:
+            e = int(torch.searchsorted(csum, torch.tensor([lo + limit], dtype=csum.dtype, device=dev), right=True).item())
+            e = max(e, start + 1)
+            ends.append(e); lo = int(csum[e - 1].item()); start = e
+        cs = [0] + [int(csum[e - 1].item()) for e in ends]
+        pieces = [(a, e, cs[i + 1] - cs[i]) for i, (a, e) in enumerate(zip([0] + ends[:-1], ends))]
+        ids_all = chunk_ids if chunk_ids is not None else torch.arange(n_sel, dtype=torch.int64, device=dev)
+        base_all = None if base is None else (base if base_is_chunk_id else torch.where(base >= 0, ids_all[base.clamp(min=0)], base))
+        by_id = True
+    total = 0
+    for a, e, need_p in pieces:
+        n_p = e - a
+        nb = int(_lib.hip_lib().hmse_workspace_bytes(STAGE_DEFLATE, n_p, C.byref(c)))
+        if ws is None or ws.numel() < nb + need_p + 4096:   # (`ws`: a caller-held workspace, e.g. the streaming front end's, reused when big enough)
+            ws = None
+            ws = _ws(nb + need_p + 4096, dev)
+        ids_p = None if ids_all is None else ids_all[a:e]
+        base_p = None if base_all is None else base_all[a:e]
+        off_p = out_off[a: e + 1] if len(pieces) == 1 else torch.zeros(n_p + 1, dtype=torch.int64, device=dev)
+        rc = _lib.hip_lib().hmse_l1_deflate_ex(_ptr(data), data.numel(), _ptr(cuts), _ptr(ids_p), _ptr(base_p), n_p, C.byref(c),
+                                               1 if by_id else 0, out.data_ptr() + total, cap - total, _ptr(off_p), _ptr(kind[a:e]), _ptr(status),
+                                               ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "hmse_l1_deflate")
+        st, tot_p = (int(v) for v in torch.stack([status[0].to(torch.int64), off_p[-1]]).tolist())
+        if st:
+            raise HmseError(-2, f"hmse_l1_deflate device status {st:#x}")
+        if len(pieces) > 1:
+            out_off[a + 1: e + 1] = off_p[1:] + total
+        total += tot_p
     return out[:total], out_off, kind
 
 

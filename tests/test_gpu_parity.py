@@ -159,6 +159,27 @@ def test_l4_minhash_memo_table_changes_nothing(orc, dev):
         assert torch.equal(ops.l4_minhash(d, cuts, cfg), ops.l4_minhash(d, cuts, cfg, memo=False)), size
 
 
+def test_l1_deflate_in_pieces_is_the_same_deflate(dev):
+    """ops.l1_deflate bounds the C-ABI call's record workspace: a selection whose per-job records exceed `ws_limit` is encoded
+    in consecutive pieces (dictionaries named by chunk id, so a piece may use a chunk of an earlier piece) — same streams,
+    offsets and kinds as the single call, with and without a selection and dictionaries."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ops
+    cfg = IngestConfig()
+    d = to_dev(corpus.wiki_synth(24 << 20, seed=42), dev)
+    cuts = ops.l2_cdc(d, cfg)
+    n = cuts.numel() - 1
+    ids = torch.arange(3, n, 2, dtype=torch.int64, device=dev)
+    sig = ops.l4_minhash(d, cuts, cfg, ids)
+    _, base = ops.l4_lsh(sig, cfg)
+    assert int((base >= 0).sum()) > 20
+    for sel, b in ((None, None), (ids, None), (ids, base)):
+        one = ops.l1_deflate(d, cuts, cfg, sel, b)
+        many = ops.l1_deflate(d, cuts, cfg, sel, b, ws_limit=12 << 20)            # ~6-12 pieces
+        for x, y in zip(one, many):
+            assert torch.equal(x, y)
+
+
 def test_l4_lsh_bit_exact(orc, dev):
     from hmse_amd import IngestConfig, ops
     cfg = IngestConfig()
