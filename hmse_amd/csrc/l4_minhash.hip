@@ -39,6 +39,9 @@ constexpr uint32_t MH_P_NONE = 1u << 30, MH_P_UNC = 1u << 31;
 #define HMSE_MH_MEMO_BITS 18
 #endif
 constexpr int MH_MEMO_BITS = HMSE_MH_MEMO_BITS;
+#ifndef HMSE_MH_CAP
+#define HMSE_MH_CAP (1u << (MH_MEMO_BITS - 1))
+#endif
 constexpr uint64_t MH_MEMO_EMPTY = ~0ull;
 constexpr uint32_t MH_SAMPLE = 256;     // lookups after which a wavefront with < 1/4 hits stops looking (per pass)
 struct MhMemo { unsigned long long* tab; uint32_t* count; uint32_t bits; uint32_t cap; uint32_t probe; };   // probe: diagnostic build only
@@ -307,7 +310,7 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   // the memo table lives in the caller's workspace and is cleared per call (a call's result and cost do not depend on
   // what ran before); a workspace of the old size (256 bytes) simply runs without one
-  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, 1u << (MH_MEMO_BITS - 1), 0};
+  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, HMSE_MH_CAP, 0};
 #ifdef HMSE_DIAG
   if (getenv("HMSE_MH_PROBE")) memo.probe = (uint32_t)atoi(getenv("HMSE_MH_PROBE"));   // 1 no re-evaluation, 2 no table reads, 4 counters
 #endif
@@ -346,7 +349,7 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
 int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
                         const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!data || !cuts_all || !uniq_all || !sig_all || !st || cap_chunks == 0 || cap_chunks > 0x7FFFFFFFull) return HMSE_EINVAL;
-  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, 1u << (MH_MEMO_BITS - 1), 0};
+  MhMemo memo{nullptr, nullptr, MH_MEMO_BITS, HMSE_MH_CAP, 0};
   if (ws && ws_bytes >= hmse_l4_minhash_workspace_bytes_impl(cap_chunks)) {   // the batch's memo table (cleared per batch: two memset nodes)
     memo.count = (uint32_t*)ws;
     memo.tab = (unsigned long long*)((uint8_t*)ws + 256);
