@@ -98,6 +98,32 @@ extern "C" size_t hmse_workspace_bytes(int stage, uint64_t n, const hmse_cfg* cf
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------
+// ---- fill kernel (see common.h: the library enqueues kernels only) -------------------------------------------------
+__global__ __launch_bounds__(256) void hmse_fill_kernel(uint32_t* __restrict__ p, uint32_t word, uint64_t n_words) {
+  const uint64_t n4 = n_words >> 2;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  const bool al16 = (((uintptr_t)p) & 15u) == 0;
+  if (al16) {
+    const uint4 v = make_uint4(word, word, word, word);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)p)[i] = v;
+    for (uint64_t i = (n4 << 2) + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = word;
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = word;
+  }
+}
+int hmse_fill_async(void* p, uint32_t byte_value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return HMSE_OK;
+  if (!p || (bytes & 3u) || (((uintptr_t)p) & 3u)) return HMSE_EINVAL;
+  const uint32_t b = byte_value & 0xFFu;
+  const uint32_t word = b | (b << 8) | (b << 16) | (b << 24);
+  const uint64_t n_words = bytes >> 2;
+  uint64_t blocks = (n_words / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hmse_fill_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>((uint32_t*)p, word, n_words);
+  return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
+}
+
 int g_hmse_prof = 0;
 namespace {
 constexpr int PROF_RING = 64;

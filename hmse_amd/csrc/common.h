@@ -77,6 +77,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* r
   return wbase + inc - v;
 }
 
+// Every byte this library clears is cleared by a KERNEL (hmse_fill_async), never by hipMemsetAsync / hipMemcpyAsync: a captured
+// chain then consists of kernel nodes only.  Reason (round 3, tools/graph_two_execs_probe.py, profiles/r3/r3_hipgraph_packet_capture.txt):
+// with ROCm 7.0's default DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 a hipGraph of the phase-A chain — kernels interleaved with small
+// memset nodes and one 4-byte device-to-device memcpy node — ran correctly on its FIRST launch and with garbage kernel
+// arguments from its SECOND launch on (the runtime replays AQL packets it recorded during the first launch).
+// `bytes` and the address must be multiples of 4.
+int hmse_fill_async(void* p, uint32_t byte_value, size_t bytes, hipStream_t stream);
+#define HMSE_FILL(p, byte_value, bytes, stream)                                        \
+  do {                                                                                 \
+    int rc__ = hmse_fill_async((p), (byte_value), (bytes), (stream));                  \
+    if (rc__ != HMSE_OK) return rc__;                                                  \
+  } while (0)
+
 // diagnostics: event pair around a stage's dominant kernel (see hmse_profile_enable)
 extern int g_hmse_prof;
 void hmse_prof_begin(int stage, hipStream_t s);
@@ -100,16 +113,23 @@ enum {
   SB_U_NEW = 4,      // stored chunks of this batch     (written by the chain)
   SB_S_OLD = 5,      // stream bytes before this batch
   SB_S_NEW = 6,      // stream bytes of this batch      (written by the chain)
-  SB_STATUS = 7,     // sticky error bits
+  SB_STATUS = 7,     // sticky error bits: once non-zero every later batch of the stream is a no-op
+  // multi-rank streaming (global chunk order = batch, rank, local index); with one rank these mirror SB_N_OLD / SB_N_NEW
+  SB_G_OLD = 8,      // chunks of ALL ranks before this batch
+  SB_G_NEW = 9,      // chunks of all ranks in this batch   (written by the chain)
+  SB_G_BASE = 10,    // global index of this rank's first chunk of this batch (written by the chain)
   SB_WORDS = 16
 };
 int hmse_l2_cdc_impl(const uint8_t* data, const uint64_t* data_off_dev, uint64_t n, const uint64_t* seg_off, uint32_t n_seg,
                      const hmse_cfg* cfg, uint64_t* cuts, uint64_t cuts_cap, uint64_t* n_cuts, uint32_t* status, void* ws,
                      size_t ws_bytes, hipStream_t stream);
-int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, const uint64_t* st,
-                       uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream);
+// digests_batch != nullptr: the digest of the batch's j-th chunk goes to digests_batch + 32 j (the rank's exchange record) instead of
+// digests_all + 32 (st[SB_N_OLD] + j)
+int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, uint8_t* digests_batch,
+                       const uint64_t* st, uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream);
+// rng: DEVICE u64[2] = {first index, count} of the digests that join the table (state + SB_N_OLD, or state + SB_G_OLD)
 int hmse_l3_index_update_dyn(const uint8_t* digests_all, uint64_t* first_occ, uint32_t* refcount, uint32_t* table, uint64_t slots,
-                             const uint64_t* st, uint64_t cap_chunks, hipStream_t stream);
+                             const uint64_t* rng, uint64_t cap_chunks, hipStream_t stream);
 int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
                         const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, void* ws, size_t ws_bytes, hipStream_t stream);
 int hmse_l4_lsh_update_dyn(const uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* tables, uint64_t slots,

@@ -1467,8 +1467,8 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   if (!out_off || !status) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
-  HMSE_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), stream));
-  if (n_sel == 0) { HMSE_HIP(hipMemsetAsync(out_off, 0, sizeof(uint64_t), stream)); return HMSE_OK; }
+  HMSE_FILL(status, 0, sizeof(uint32_t), stream);
+  if (n_sel == 0) { HMSE_FILL(out_off, 0, sizeof(uint64_t), stream); return HMSE_OK; }
   if (!data || !cuts || !out || !kind) return HMSE_EINVAL;
   if (n_sel > 0x3FFFFFFFull) return HMSE_EINVAL;
   Ws w = carve(ws, n_sel);
@@ -1476,9 +1476,9 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   // record area = whatever follows the fixed part; a job whose record does not fit sets status bit 1
   // (needed: sum over selected chunks of rec_size(len) ~ 5*len + 1.6 KiB, twice where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
-  HMSE_HIP(hipMemsetAsync(w.counters, 0, 32 * sizeof(uint32_t), stream));
-  HMSE_HIP(hipMemsetAsync(w.len_full, 0, n_sel * sizeof(uint32_t), stream));
-  HMSE_HIP(hipMemsetAsync(w.len_delta, 0, n_sel * sizeof(uint32_t), stream));
+  HMSE_FILL(w.counters, 0, 32 * sizeof(uint32_t), stream);
+  HMSE_FILL(w.len_full, 0, n_sel * sizeof(uint32_t), stream);
+  HMSE_FILL(w.len_delta, 0, n_sel * sizeof(uint32_t), stream);
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
   rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off, n_dev);
   HMSE_LAUNCH_CHECK();

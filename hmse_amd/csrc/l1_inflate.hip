@@ -1010,11 +1010,11 @@ extern "C" int hmse_l1_inflate(const uint8_t* streams, uint64_t streams_bytes, c
   if (!status) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  HMSE_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), stream));
+  HMSE_FILL(status, 0, sizeof(uint32_t), stream);
   if (n_sel == 0) return HMSE_OK;
   if (!streams || !stream_off || !kind || !raw_off || !raw_out || n_sel > 0x7FFFFFFFull) return HMSE_EINVAL;
   if (!ws || ws_bytes < hmse_l1_inflate_workspace_bytes_impl(n_sel)) return HMSE_ENOSPC;
-  HMSE_HIP(hipMemsetAsync(ws, 0, hmse_l1_inflate_workspace_bytes_impl(n_sel), stream));
+  HMSE_FILL(ws, 0, hmse_l1_inflate_workspace_bytes_impl(n_sel), stream);
   Args a;
   a.streams = streams; a.streams_bytes = streams_bytes; a.stream_off = stream_off; a.stream_len = stream_len;
   a.kind = kind; a.base = base; a.n_sel = (uint32_t)n_sel;
@@ -1048,7 +1048,7 @@ extern "C" int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const
   if (!status) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  HMSE_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), stream));
+  HMSE_FILL(status, 0, sizeof(uint32_t), stream);
   if (n_chunks == 0) return HMSE_OK;
   if (!cuts || !slot_of_chunk || !raw_off || !raw || !data_out) return HMSE_EINVAL;
   if (n_chunks > 0x7FFFFFFFull) return HMSE_EINVAL;

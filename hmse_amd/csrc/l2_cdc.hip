@@ -403,6 +403,8 @@ __global__ __launch_bounds__(256) void l2_copy_kernel(const uint64_t* __restrict
     if (dst + i < cuts_cap) cuts[dst + i] = src[i];
 }
 
+__global__ void l2_publish_status_kernel(const L2Header* __restrict__ hdr, uint32_t* __restrict__ status) { *status = hdr->status; }
+
 // ---- host side -----------------------------------------------------------------------------------
 
 static uint64_t l2_cand_cap(uint64_t n, const hmse_cfg* cfg) {
@@ -454,7 +456,7 @@ int hmse_l2_cdc_impl(const uint8_t* data, const uint64_t* data_off_dev, uint64_t
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   L2Ws w = l2_carve(ws, ws_bytes, n, n_seg, cfg);
   if (!w.ok) return HMSE_ENOSPC;
-  HMSE_HIP(hipMemsetAsync(w.hdr, 0, sizeof(L2Header), stream));
+  HMSE_FILL(w.hdr, 0, sizeof(L2Header), stream);
   uint32_t ms_hi, ml_hi;
   hmse_cdc_masks_hi(cfg, &ms_hi, &ml_hi);
   const uint64_t n_tiles = (n + L2_TILE - 1) / L2_TILE;
@@ -477,6 +479,7 @@ int hmse_l2_cdc_impl(const uint8_t* data, const uint64_t* data_off_dev, uint64_t
                                                           cuts, cuts_cap);
     HMSE_LAUNCH_CHECK();
   }
-  HMSE_HIP(hipMemcpyAsync(status, &w.hdr->status, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+  l2_publish_status_kernel<<<dim3(1), dim3(1), 0, stream>>>(w.hdr, status);   // (a kernel, not a memcpy node: common.h)
+  HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

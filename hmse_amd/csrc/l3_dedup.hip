@@ -29,7 +29,7 @@ template <int KEY_U4>
 __global__ __launch_bounds__(256) void fo_insert_kernel(const uint8_t* __restrict__ keys, size_t stride,
                                                          const uint32_t* __restrict__ hashes, uint64_t i0, uint64_t n, uint32_t* table,
                                                          uint32_t mask, const uint64_t* __restrict__ st = nullptr) {
-  if (st) { i0 = st[SB_N_OLD]; n = st[SB_N_NEW]; }
+  if (st) { i0 = st[0]; n = st[1]; }   // captured chain: {first index, count} read on the device
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
   const uint32_t i = (uint32_t)(i0 + i64);   // entries [i0, i0 + n) join a table that may already hold [0, i0)
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void dedup_lookup_kernel(const uint8_t* __rest
                                                             const uint32_t* __restrict__ table, uint32_t mask,
                                                             uint64_t* __restrict__ first_occ, uint32_t* __restrict__ refcount,
                                                             const uint64_t* __restrict__ st = nullptr) {
-  if (st) { i0 = st[SB_N_OLD]; n = st[SB_N_NEW]; }
+  if (st) { i0 = st[0]; n = st[1]; }   // captured chain: {first index, count} read on the device
   const uint64_t i64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= n) return;
   const uint32_t i = (uint32_t)(i0 + i64);
@@ -96,8 +96,8 @@ extern "C" int hmse_l3_dedup(const uint8_t* digests_all, uint64_t n_all, uint64_
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
   uint32_t* table = (uint32_t*)ws;
-  HMSE_HIP(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, stream));
-  if (refcount) HMSE_HIP(hipMemsetAsync(refcount, 0, n_all * sizeof(uint32_t), stream));
+  HMSE_FILL(table, 0xFF, (size_t)slots * 4, stream);
+  if (refcount) HMSE_FILL(refcount, 0, n_all * sizeof(uint32_t), stream);
   const uint32_t blocks = (uint32_t)((n_all + 255) / 256);
   fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, 0, n_all, table, slots - 1);
   HMSE_LAUNCH_CHECK();
@@ -118,10 +118,10 @@ extern "C" int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, 
   if (n_old + n_new >= 0x7FFFFFFFull || 2 * (n_old + n_new) > slots) return HMSE_ENOSPC;   // load factor <= 0.5
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  if (n_old == 0) HMSE_HIP(hipMemsetAsync(table, 0xFF, (size_t)slots * 4, stream));
+  if (n_old == 0) HMSE_FILL(table, 0xFF, (size_t)slots * 4, stream);
   if (n_new == 0) return HMSE_OK;
   if (!digests_all || !first_occ) return HMSE_EINVAL;
-  if (refcount) HMSE_HIP(hipMemsetAsync(refcount + n_old, 0, n_new * sizeof(uint32_t), stream));
+  if (refcount) HMSE_FILL(refcount + n_old, 0, n_new * sizeof(uint32_t), stream);
   const uint32_t blocks = (uint32_t)((n_new + 255) / 256);
   fo_insert_kernel<2><<<dim3(blocks), dim3(256), 0, stream>>>(digests_all, 32, nullptr, n_old, n_new, table, (uint32_t)(slots - 1));
   HMSE_LAUNCH_CHECK();
@@ -132,12 +132,13 @@ extern "C" int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, 
 
 __global__ __launch_bounds__(256) void zero_refcount_kernel(uint32_t* __restrict__ refcount, const uint64_t* __restrict__ st) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < st[SB_N_NEW]) refcount[st[SB_N_OLD] + i] = 0;
+  if (i < st[1]) refcount[st[0] + i] = 0;
 }
 // captured chain: range from the device state, grids sized for cap_chunks (the table is never cleared here: the caller's
 // first hmse_l3_index_update / a memset did that)
 int hmse_l3_index_update_dyn(const uint8_t* digests_all, uint64_t* first_occ, uint32_t* refcount, uint32_t* table, uint64_t slots,
-                             const uint64_t* st, uint64_t cap_chunks, hipStream_t stream) {
+                             const uint64_t* rng, uint64_t cap_chunks, hipStream_t stream) {
+  const uint64_t* st = rng;
   if (!digests_all || !first_occ || !refcount || !table || !st || slots < 1024 || (slots & (slots - 1)) || slots > (1ull << 31)) return HMSE_EINVAL;
   const uint32_t blocks = (uint32_t)((cap_chunks + 255) / 256);
   zero_refcount_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(refcount, st);

@@ -49,8 +49,10 @@ __device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) 
 __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                          const uint64_t* __restrict__ cuts, uint64_t n_chunks,
                                                          uint8_t* __restrict__ digests, unsigned long long* counter,
-                                                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ sbst) {
-  if (sbst) { cuts += sbst[SB_N_OLD]; digests += 32 * sbst[SB_N_OLD]; n_chunks = sbst[SB_N_NEW]; }   // captured chain: this batch's chunks
+                                                         const uint32_t* __restrict__ order, const uint64_t* __restrict__ sbst,
+                                                         uint32_t batch_relative) {
+  // captured chain: this batch's chunks; their digests go behind the earlier batches', or (batch_relative) into a per-batch buffer
+  if (sbst) { cuts += sbst[SB_N_OLD]; if (!batch_relative) digests += 32 * sbst[SB_N_OLD]; n_chunks = sbst[SB_N_NEW]; }
   const uint32_t lane = lane_id();
   // per-lane chunk state
   uint64_t idx = 0, cur = 0, len = 0;
@@ -203,7 +205,7 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   uint32_t* order = nullptr;
   if (ws_bytes >= hmse_l3_sha256_workspace_bytes_impl(n_chunks) && n_chunks > 4096) {
     order = bins + ORD_BINS;
-    HMSE_HIP(hipMemsetAsync(ws, 0, 256 + ORD_BINS * 4, stream));
+    HMSE_FILL(ws, 0, 256 + ORD_BINS * 4, stream);
     uint64_t hb = (n_chunks + 255) / 256;
     if (hb > 1024) hb = 1024;
     ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts, n_chunks, bins, nullptr);
@@ -211,7 +213,7 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
     ord_scatter_kernel<<<dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts, n_chunks, bins, order, nullptr);
     HMSE_LAUNCH_CHECK();
   } else {
-    HMSE_HIP(hipMemsetAsync(ws, 0, 8, stream));
+    HMSE_FILL(ws, 0, 8, stream);
   }
   // persistent grid: one chunk per lane while chunks are scarce (the longest chunk bounds the run time
   // anyway), capped at 4 workgroups of 256 per CU (4 waves per SIMD saturate the VALU) so that on large
@@ -219,7 +221,7 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
   uint64_t blocks = (n_chunks + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   PROF_BEGIN(HMSE_STAGE_L3_SHA256, stream);
-  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws, order, nullptr);
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n, cuts, n_chunks, digests, (unsigned long long*)ws, order, nullptr, 0u);
   PROF_END(HMSE_STAGE_L3_SHA256, stream);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
@@ -227,13 +229,13 @@ extern "C" int hmse_l3_sha256(const uint8_t* data, uint64_t n, const uint64_t* c
 
 // Captured chain: the chunks [st[SB_N_OLD], + st[SB_N_NEW]) of cuts_all, counts read on the device, grids sized for cap_chunks.
 // Always hands chunks out longest first (same digests either way: the order only schedules).
-int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, const uint64_t* st,
-                       uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!data || !cuts_all || !digests_all || !st || cap_chunks == 0 || cap_chunks >= 0xFFFFFFFFull) return HMSE_EINVAL;
+int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, uint8_t* digests_all, uint8_t* digests_batch,
+                       const uint64_t* st, uint64_t cap_chunks, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!data || !cuts_all || (!digests_all && !digests_batch) || !st || cap_chunks == 0 || cap_chunks >= 0xFFFFFFFFull) return HMSE_EINVAL;
   if (!ws || ws_bytes < hmse_l3_sha256_workspace_bytes_impl(cap_chunks)) return HMSE_ENOSPC;
   uint32_t* bins = (uint32_t*)((uint8_t*)ws + 256);
   uint32_t* order = bins + ORD_BINS;
-  HMSE_HIP(hipMemsetAsync(ws, 0, 256 + ORD_BINS * 4, stream));
+  HMSE_FILL(ws, 0, 256 + ORD_BINS * 4, stream);
   uint64_t hb = (cap_chunks + 255) / 256;
   if (hb > 1024) hb = 1024;
   ord_hist_kernel<<<dim3((uint32_t)hb), dim3(256), 0, stream>>>(cuts_all, 0, bins, st);
@@ -241,7 +243,8 @@ int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts
   ord_scatter_kernel<<<dim3((uint32_t)((cap_chunks + 255) / 256)), dim3(256), 0, stream>>>(cuts_all, 0, bins, order, st);
   uint64_t blocks = (cap_chunks + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n_cap, cuts_all, 0, digests_all, (unsigned long long*)ws, order, st);
+  l3_sha256_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(data, n_cap, cuts_all, 0, digests_batch ? digests_batch : digests_all, (unsigned long long*)ws, order, st,
+                                                                      digests_batch ? 1u : 0u);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
 }

@@ -122,7 +122,7 @@ extern "C" int hmse_l4_lsh(const uint32_t* sig, uint64_t n_sel, const hmse_cfg* 
   if (!ws || ws_bytes < need) return HMSE_ENOSPC;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();  // drop stale errors of earlier runtime calls made by the host process
-  HMSE_HIP(hipMemsetAsync(ws, 0xFF, need, stream));
+  HMSE_FILL(ws, 0xFF, need, stream);
   const uint64_t nb = n_sel * cfg->bands;
   lsh_keys_kernel<<<dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, stream>>>(sig, 0, n_sel, cfg->bands, cfg->rows, band_keys);
   HMSE_LAUNCH_CHECK();
@@ -149,7 +149,7 @@ extern "C" int hmse_l4_lsh_update(const uint32_t* sig_all, uint64_t n_old, uint6
   if (2 * (n_old + n_new) > slots) return HMSE_ENOSPC;   // load factor <= 0.5
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  if (n_old == 0) HMSE_HIP(hipMemsetAsync(tables, 0xFF, (size_t)slots * 4 * cfg->bands, stream));
+  if (n_old == 0) HMSE_FILL(tables, 0xFF, (size_t)slots * 4 * cfg->bands, stream);
   if (n_new == 0) return HMSE_OK;
   if (!sig_all || !band_keys) return HMSE_EINVAL;
   const uint64_t nb = n_new * cfg->bands;

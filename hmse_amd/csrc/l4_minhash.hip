@@ -317,8 +317,8 @@ extern "C" int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* 
   if (ws && ws_bytes >= hmse_l4_minhash_workspace_bytes_impl(n_sel)) {
     memo.count = (uint32_t*)ws;
     memo.tab = (unsigned long long*)((uint8_t*)ws + 256);
-    HMSE_HIP(hipMemsetAsync(ws, 0, 256, stream));
-    HMSE_HIP(hipMemsetAsync(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream));
+    HMSE_FILL(ws, 0, 256, stream);
+    HMSE_FILL(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream);
   }
   PROF_BEGIN(HMSE_STAGE_L4_MINHASH, stream);
 #ifdef HMSE_DIAG
@@ -353,8 +353,8 @@ int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cut
   if (ws && ws_bytes >= hmse_l4_minhash_workspace_bytes_impl(cap_chunks)) {   // the batch's memo table (cleared per batch: two memset nodes)
     memo.count = (uint32_t*)ws;
     memo.tab = (unsigned long long*)((uint8_t*)ws + 256);
-    HMSE_HIP(hipMemsetAsync(ws, 0, 256, stream));
-    HMSE_HIP(hipMemsetAsync(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream));
+    HMSE_FILL(ws, 0, 256, stream);
+    HMSE_FILL(memo.tab, 0xFF, (size_t)8 << MH_MEMO_BITS, stream);
   }
   l4_minhash_kernel<1024, 1><<<dim3((uint32_t)cap_chunks), dim3(1024), 0, stream>>>(data, n_cap, cuts_all, uniq_all, 0, cfg->seed_base, sig_all, st, memo, 0);
   HMSE_LAUNCH_CHECK();

@@ -134,7 +134,7 @@ extern "C" int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream
   if (n_chunks > 0xFFFFFFFEull || n_unique > n_chunks) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  HMSE_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t), stream));
+  HMSE_FILL(status, 0, sizeof(uint32_t), stream);
   if (n_chunks == 0) return HMSE_OK;
   if (!stream_off || !kind || !uniq_ids || !cuts || !rec_off || !index || !chunk_map || !ptr_index) return HMSE_EINVAL;
   if (n_unique && (!streams || !blob)) return HMSE_EINVAL;
@@ -147,7 +147,7 @@ extern "C" int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream
   a.shard = shard; a.shard_bases = shard_bases; a.n_shards = n_shards; a.rec_off = rec_off; a.lba_unit = lba_unit; a.ptr_index = ptr_index;
   a.blob = blob; a.blob_bytes = blob_bytes; a.index = (uint8_t*)index; a.chunk_map = (uint8_t*)chunk_map; a.pointers = (uint8_t*)pointers;
   a.n_pointers = n_pointers; a.slot_of = (uint32_t*)ws; a.status = status;
-  HMSE_HIP(hipMemsetAsync(a.slot_of, 0xFF, 4 * n_chunks, stream));
+  HMSE_FILL(a.slot_of, 0xFF, 4 * n_chunks, stream);
   PROF_BEGIN(HMSE_STAGE_MANIFEST_PACK, stream);
   if (n_unique) records_kernel<<<dim3((uint32_t)n_unique), dim3(256), 0, stream>>>(a);
   PROF_END(HMSE_STAGE_MANIFEST_PACK, stream);

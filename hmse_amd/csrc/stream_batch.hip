@@ -1,47 +1,99 @@
-// stream_batch.hip — one batch of the streaming front end as ONE enqueue without a host read (BASELINE.json
-// configs[4] "hipGraph-captured per-batch pipeline"; the reference's batch loop README.md:1519-1580).
+// stream_batch.hip — one batch of the streaming front end without a host read (BASELINE.json configs[4]
+// "4 x 10 GB streamed, 8 x MI355X, hipGraph-captured per-batch pipeline"; the reference's batch loop README.md:1519-1580).
 //
 // hmse_amd/stream.py's eager path reads device counts on the host between stages (chunk count, stored-chunk count, stream
 // bytes) to size the next launch.  Here every stage takes its ranges from a small state block in HBM (common.h, SB_*), grids
-// and workspaces are sized for the worst case of the batch (n / min_size chunks), and the chain ends by advancing the state
-// itself (streams are appended to `out` behind the earlier batches' at state[SB_S_OLD]) — so the whole sequence L2 -> L3 (hash + persistent index) -> stored-chunk selection -> L4 (MinHash + persistent band
-// tables) -> L1 (dictionary DEFLATE) -> index tails can be captured into a hipGraph once and replayed for every batch of that
-// size; the host reads the state block when it wants the counts (at the end of the stream, or per batch to fetch the streams).
-// Results equal the eager path's bit for bit (tests/test_gpu_stream.py).
+// and workspaces are sized for the worst case of the batch (bytes / min_size chunks), and the chain ends by advancing the
+// state itself — so the sequence L2 -> L3 hash | digest exchange | L3 persistent index -> stored-chunk selection -> L4
+// (MinHash + persistent band tables) -> L1 (dictionary DEFLATE) -> index tails can be captured into hipGraphs once and
+// replayed for every batch; the host reads the state block when it wants the counts (at the end of the stream).
+//
+// The chain has TWO phases around the one exchange step of a multi-rank stream (one process per GPU):
+//   hmse_stream_piece_hash    this rank's piece of the batch: L2 cut points, cuts appended, SHA-256 of the new chunks
+//                             -> the rank's EXCHANGE ROW {u64 count, 24 B pad, cap x 32 B digests}
+//   (all-gather of the rows over RCCL/xGMI — the only collective; with one rank the row IS the gathered array)
+//   hmse_stream_piece_encode  rows of all ranks -> global digest array in (batch, rank, local) order, persistent L3 table
+//                             (every rank runs the same order-independent first-occurrence rule on the same rows), this
+//                             rank's stored chunks, L4, L1, index tails, state advanced
+// hmse_stream_batch (one rank) runs both back to back.  Results equal the eager path's bit for bit (tests/test_gpu_stream.py),
+// and a multi-rank stream equals the oracle's (n_ranks, piece_bytes) pipeline (tests/test_gpu_stream_dist.py).
+// A batch that hits a capacity limit or a stage error sets the sticky state[SB_STATUS] and is dropped; every later batch of
+// the stream is then a no-op (nothing is appended to an index that is no longer consistent), the host sees the status in finish().
 #include "common.h"
 
 namespace sb {
 
-// cuts of the batch (batch-local, from L2) -> global cut array; n_new
+constexpr uint32_t ROW_HDR = 32;   // bytes in front of a row's digests: u64 chunk count + padding (keeps the digests 32-byte aligned)
+
+// cuts of the piece (piece-local, from L2) -> this rank's cut array; N_NEW; the row's count.  n_cuts == nullptr: an empty piece.
 __global__ __launch_bounds__(256) void append_cuts_kernel(const uint64_t* __restrict__ local, const uint64_t* __restrict__ n_cuts,
-                                                           uint64_t* __restrict__ cuts_all, uint64_t* st, uint64_t max_chunks) {
+                                                           const uint32_t* __restrict__ l2_status, uint64_t* __restrict__ cuts_all,
+                                                           uint64_t* st, uint64_t max_chunks, uint64_t cap, uint8_t* row) {
   const uint64_t n_old = st[SB_N_OLD], off = st[SB_OFF];
-  uint64_t n_new = *n_cuts;
-  const bool fits = n_old + n_new <= max_chunks;
-  if (!fits) n_new = 0;   // capacity exceeded: the batch is dropped and flagged, nothing is written out of bounds
+  uint64_t n_new = n_cuts ? *n_cuts : 0ull;
+  uint64_t err = 0;
+  if (st[SB_STATUS]) n_new = 0;                                      // an earlier batch failed: this one is a no-op
+  else if (l2_status && *l2_status) { err = 4ull; n_new = 0; }       // the cut list is not trustworthy: drop the batch
+  else if (n_new > cap || n_old + n_new > max_chunks) { err = 1ull; n_new = 0; }   // capacity: dropped and flagged, nothing out of bounds
   for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n_new; j += (uint64_t)gridDim.x * 256) cuts_all[n_old + 1 + j] = local[j + 1] + off;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st[SB_N_NEW] = n_new;
-    if (!fits) st[SB_STATUS] |= 1ull;
+    if (err) st[SB_STATUS] |= err;
+    *(uint64_t*)row = n_new;
   }
 }
 
-// stored chunks of the batch = chunks that are their own first occurrence: ascending append to uniq_all, count -> state.
-// One workgroup: the batch has at most a few hundred thousand chunks.
-__global__ __launch_bounds__(1024) void select_uniq_kernel(const uint64_t* __restrict__ first_occ, uint64_t* __restrict__ uniq_all,
+// rows of all ranks -> digests_g[G_OLD + prefix(rank) + j]; G_NEW, G_BASE; local chunk -> global index.  One thread per
+// (rank, chunk slot, 16-byte half); every thread derives the same counts from the row headers.
+__global__ __launch_bounds__(256) void ingest_rows_kernel(const uint8_t* __restrict__ rows, uint64_t row_bytes, uint32_t world, uint32_t rank,
+                                                           uint64_t cap, uint8_t* __restrict__ digests_g, uint64_t max_chunks_g,
+                                                           uint64_t* __restrict__ gidx, uint64_t* st) {
+  const uint64_t g_old = st[SB_G_OLD];
+  const bool dead = st[SB_STATUS] != 0;                              // this rank is out (its own row says 0 chunks already)
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t r = (uint32_t)(tid / (2 * cap));
+  const uint64_t j = (tid % (2 * cap)) >> 1;
+  const uint32_t half = (uint32_t)(tid & 1);
+  uint64_t total = 0, before = 0, mine_before = 0, cnt_r = 0;
+  bool bad = false;
+  for (uint32_t q = 0; q < world; q++) {
+    uint64_t c = *(const uint64_t*)(rows + (size_t)q * row_bytes);
+    if (c > cap) { bad = true; c = 0; }                              // a row that does not come from this build's phase A
+    if (q < r) before += c;
+    if (q < rank) mine_before += c;
+    if (q == r) cnt_r = c;
+    total += c;
+  }
+  const bool over = g_old + total > max_chunks_g;
+  if (dead || bad || over) total = 0;
+  if (r < world && total && j < cnt_r) {
+    const uint4 v = *(const uint4*)(rows + (size_t)r * row_bytes + ROW_HDR + 32 * j + 16 * half);
+    *(uint4*)(digests_g + 32 * (g_old + before + j) + 16 * half) = v;
+  }
+  if (gidx && total && r == rank && half == 0 && j < cnt_r) gidx[st[SB_N_OLD] + j] = g_old + mine_before + j;
+  if (tid == 0) {
+    st[SB_G_NEW] = total;
+    st[SB_G_BASE] = g_old + mine_before;
+    if (!dead && (bad || over)) { st[SB_STATUS] |= bad ? 8ull : 1ull; st[SB_N_NEW] = 0; }
+  }
+}
+
+// stored chunks of the piece = this rank's chunks that are their own (global) first occurrence: ascending append of their
+// LOCAL chunk ids to uniq_all, count -> state.  One workgroup: a piece has at most a few hundred thousand chunks.
+__global__ __launch_bounds__(1024) void select_uniq_kernel(const uint64_t* __restrict__ first_occ_g, uint64_t* __restrict__ uniq_all,
                                                             uint64_t* st, uint64_t max_unique) {
   __shared__ uint32_t red[1024 / 64 + 1];
   __shared__ uint64_t run;
-  const uint64_t n_old = st[SB_N_OLD], n_new = st[SB_N_NEW], u_old = st[SB_U_OLD];
+  const uint64_t n_old = st[SB_N_OLD], n_new = st[SB_N_NEW], u_old = st[SB_U_OLD], g_base = st[SB_G_BASE];
   if (threadIdx.x == 0) run = 0;
   __syncthreads();
   for (uint64_t b0 = 0; b0 < n_new; b0 += 1024) {
-    const uint64_t i = n_old + b0 + threadIdx.x;
-    const bool mine = b0 + threadIdx.x < n_new && first_occ[i] == i;
+    const uint64_t j = b0 + threadIdx.x;
+    const bool mine = j < n_new && first_occ_g[g_base + j] == g_base + j;
     uint32_t total;
     const uint32_t ex = block_exclusive_scan<1024>(mine ? 1u : 0u, red, &total);
     const uint64_t r = run;
-    if (mine && u_old + r + ex < max_unique) uniq_all[u_old + r + ex] = i;
+    if (mine && u_old + r + ex < max_unique) uniq_all[u_old + r + ex] = n_old + j;
     __syncthreads();
     if (threadIdx.x == 0) run = r + total;
     __syncthreads();
@@ -53,7 +105,7 @@ __global__ __launch_bounds__(1024) void select_uniq_kernel(const uint64_t* __res
   }
 }
 
-// the batch's DEFLATE selection as contiguous arrays: chunk ids of its stored chunks and their dictionaries as chunk ids
+// the piece's DEFLATE selection as contiguous arrays: chunk ids of its stored chunks and their dictionaries as chunk ids
 __global__ __launch_bounds__(256) void prep_deflate_kernel(const uint64_t* __restrict__ uniq_all, const int64_t* __restrict__ base_all,
                                                             const uint64_t* __restrict__ st, uint64_t* __restrict__ sel_ids,
                                                             int64_t* __restrict__ sel_base, uint64_t* __restrict__ n_sel) {
@@ -66,10 +118,10 @@ __global__ __launch_bounds__(256) void prep_deflate_kernel(const uint64_t* __res
   sel_base[k] = b >= 0 ? (int64_t)uniq_all[b] : -1;
 }
 
-// tails of kind / stream offsets, then the state moves on to the next batch
+// tails of kind / stream offsets
 __global__ __launch_bounds__(256) void commit_kernel(const uint8_t* __restrict__ kind_b, const uint64_t* __restrict__ out_off_b, uint64_t cap_sel,
                                                       uint8_t* __restrict__ kind_all, uint64_t* __restrict__ stream_off_all,
-                                                      const uint32_t* __restrict__ dfl_status, const uint32_t* __restrict__ l2_status, uint64_t* st) {
+                                                      const uint32_t* __restrict__ dfl_status, uint64_t* st) {
   const uint64_t u_old = st[SB_U_OLD], nu = st[SB_U_NEW], s_old = st[SB_S_OLD];
   const uint64_t total = nu ? out_off_b[cap_sel] : 0ull;
   for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < nu; k += (uint64_t)gridDim.x * 256) {
@@ -79,19 +131,22 @@ __global__ __launch_bounds__(256) void commit_kernel(const uint8_t* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st[SB_S_NEW] = total;
     if (*dfl_status) st[SB_STATUS] |= (uint64_t)*dfl_status << 8;
-    if (*l2_status) st[SB_STATUS] |= 4ull;
   }
 }
-__global__ void advance_kernel(uint64_t* st, uint64_t batch_bytes) {
-  st[SB_OFF] += batch_bytes;
+// the state moves on to the next batch — unless this one (or an earlier one) failed: then the counters stay where the last
+// good batch left them
+__global__ void advance_kernel(uint64_t* st, uint64_t piece_bytes) {
+  if (st[SB_STATUS]) return;
+  st[SB_OFF] += piece_bytes;
   st[SB_N_OLD] += st[SB_N_NEW];
   st[SB_U_OLD] += st[SB_U_NEW];
   st[SB_S_OLD] += st[SB_S_NEW];
+  st[SB_G_OLD] += st[SB_G_NEW];
 }
 
 struct Ws {
   uint64_t* cuts_local; uint64_t* n_cuts; uint32_t* l2_status; uint64_t* sel_ids; int64_t* sel_base; uint64_t* n_sel;
-  uint64_t* out_off; uint8_t* kind; uint32_t* dfl_status;
+  uint64_t* out_off; uint8_t* kind; uint32_t* dfl_status; uint8_t* row;
   uint8_t* l2_ws; size_t l2_bytes; uint8_t* sha_ws; size_t sha_bytes; uint8_t* mh_ws; size_t mh_bytes; uint8_t* dfl_ws; size_t dfl_bytes;
   size_t total;
 };
@@ -103,12 +158,14 @@ size_t hmse_l3_sha256_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t n_chunks);
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_chunks, const hmse_cfg* cfg);
 
-static uint64_t sb_cap_chunks(uint64_t batch_bytes, uint32_t n_seg, const hmse_cfg* cfg) { return batch_bytes / cfg->min_size + n_seg + 2; }
+static uint32_t sb_n_seg(uint64_t bytes, const hmse_cfg* cfg) { return (uint32_t)((bytes + cfg->seg_size - 1) / cfg->seg_size); }
+// worst-case chunk count of a piece of `cap_bytes` (the NOMINAL piece size: it sizes rows, grids and workspaces for every piece)
+static uint64_t sb_cap_chunks(uint64_t cap_bytes, const hmse_cfg* cfg) { return cap_bytes / cfg->min_size + sb_n_seg(cap_bytes, cfg) + 2; }
 
-static sb::Ws sb_carve(void* ws, uint64_t batch_bytes, uint32_t n_seg, const hmse_cfg* cfg) {
+static sb::Ws sb_carve(void* ws, uint64_t cap_bytes, const hmse_cfg* cfg) {
   WsCarver w(ws, ~(size_t)0);
   sb::Ws r;
-  const uint64_t cap = sb_cap_chunks(batch_bytes, n_seg, cfg);
+  const uint64_t cap = sb_cap_chunks(cap_bytes, cfg);
   r.cuts_local = w.take<uint64_t>(cap + 1);
   r.n_cuts = w.take<uint64_t>(1);
   r.l2_status = w.take<uint32_t>(1);
@@ -118,60 +175,142 @@ static sb::Ws sb_carve(void* ws, uint64_t batch_bytes, uint32_t n_seg, const hms
   r.out_off = w.take<uint64_t>(cap + 1);
   r.kind = w.take<uint8_t>(cap);
   r.dfl_status = w.take<uint32_t>(1);
-  r.l2_bytes = hmse_l2_workspace_bytes_impl(batch_bytes, n_seg, cfg) + 4096;
+  r.row = w.take<uint8_t>(sb::ROW_HDR + 32 * cap);
+  r.l2_bytes = hmse_l2_workspace_bytes_impl(cap_bytes, sb_n_seg(cap_bytes, cfg), cfg) + 4096;
   r.l2_ws = w.take<uint8_t>(r.l2_bytes);
   r.sha_bytes = hmse_l3_sha256_workspace_bytes_impl(cap);
   r.sha_ws = w.take<uint8_t>(r.sha_bytes);
   r.mh_bytes = hmse_l4_minhash_workspace_bytes_impl(cap);
   r.mh_ws = w.take<uint8_t>(r.mh_bytes);
   // DEFLATE: fixed part + the record area for the worst case (every chunk stored, every one with a dictionary)
-  r.dfl_bytes = hmse_l1_deflate_workspace_bytes_impl(cap, cfg) + 2 * (5 * batch_bytes + 1600 * cap) + 4096;
+  r.dfl_bytes = hmse_l1_deflate_workspace_bytes_impl(cap, cfg) + 2 * (5 * cap_bytes + 1600 * cap) + 4096;
   r.dfl_ws = w.take<uint8_t>(r.dfl_bytes);
   r.total = w.off;
   return r;
 }
 
-extern "C" uint64_t hmse_stream_batch_workspace_bytes(uint64_t batch_bytes, const hmse_cfg* cfg) {
-  if (hmse_cfg_validate_impl(cfg) != 0 || batch_bytes == 0) return 0;
-  const uint32_t n_seg = (uint32_t)((batch_bytes + cfg->seg_size - 1) / cfg->seg_size);
-  return sb_carve(nullptr, batch_bytes, n_seg, cfg).total;
+extern "C" uint64_t hmse_stream_batch_workspace_bytes(uint64_t cap_bytes, const hmse_cfg* cfg) {
+  if (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0) return 0;
+  return sb_carve(nullptr, cap_bytes, cfg).total;
 }
 
+extern "C" uint64_t hmse_stream_row_bytes(uint64_t cap_bytes, const hmse_cfg* cfg) {
+  if (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0) return 0;
+  return sb::ROW_HDR + 32 * sb_cap_chunks(cap_bytes, cfg);
+}
+
+// ---- phase A ------------------------------------------------------------------------------------------------------------
+static int piece_hash(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const uint64_t* seg_off, uint32_t n_seg,
+                      const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks, uint8_t* row, const sb::Ws& w,
+                      hipStream_t stream) {
+  const uint64_t cap = sb_cap_chunks(cap_bytes, cfg);
+  if (piece_bytes == 0) {   // this rank has nothing in this batch: N_NEW = 0, an empty row
+    sb::append_cuts_kernel<<<dim3(1), dim3(256), 0, stream>>>(nullptr, nullptr, nullptr, cuts_all, state, max_chunks, cap, row);
+    HMSE_LAUNCH_CHECK();
+    return HMSE_OK;
+  }
+  int rc;
+  // L2 on the piece's bytes (data + state[SB_OFF], read on the device)
+  if ((rc = hmse_l2_cdc_impl(data, state + SB_OFF, piece_bytes, seg_off, n_seg, cfg, w.cuts_local, cap + 1, w.n_cuts, w.l2_status, w.l2_ws,
+                             w.l2_bytes, stream)) != HMSE_OK) return rc;
+  uint32_t ab = (uint32_t)((cap + 255) / 256); if (ab > 1024) ab = 1024;
+  sb::append_cuts_kernel<<<dim3(ab), dim3(256), 0, stream>>>(w.cuts_local, w.n_cuts, w.l2_status, cuts_all, state, max_chunks, cap, row);
+  // L3: digests of the new chunks go into the exchange row
+  if ((rc = hmse_l3_sha256_dyn(data, data_cap, cuts_all, nullptr, row + sb::ROW_HDR, state, cap, w.sha_ws, w.sha_bytes, stream)) != HMSE_OK) return rc;
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+// ---- phase B ------------------------------------------------------------------------------------------------------------
+static int piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state,
+                        const uint8_t* rows, uint32_t world, uint32_t rank, const uint64_t* cuts_all, uint64_t* gidx, uint8_t* digests_g,
+                        uint64_t max_chunks_g, uint64_t* first_occ_g, uint32_t* refcount_g, uint32_t* l3_table, uint64_t l3_slots,
+                        uint64_t* uniq_all, uint64_t max_unique, uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* lsh_tables,
+                        uint64_t lsh_slots, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out, uint64_t out_cap, const sb::Ws& w,
+                        hipStream_t stream) {
+  const uint64_t cap = sb_cap_chunks(cap_bytes, cfg);
+  const uint64_t row_bytes = sb::ROW_HDR + 32 * cap;
+  int rc;
+  const uint64_t gthreads = 2ull * world * cap;
+  sb::ingest_rows_kernel<<<dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, stream>>>(rows, row_bytes, world, rank, cap, digests_g, max_chunks_g,
+                                                                                            gidx, state);
+  // persistent L3 index over the global chunk order: every rank inserts the same digests under the same indices
+  if ((rc = hmse_l3_index_update_dyn(digests_g, first_occ_g, refcount_g, l3_table, l3_slots, state + SB_G_OLD, (uint64_t)world * cap, stream)) != HMSE_OK)
+    return rc;
+  sb::select_uniq_kernel<<<dim3(1), dim3(1024), 0, stream>>>(first_occ_g, uniq_all, state, max_unique);
+  // L4: signatures of the new stored chunks, persistent band tables (this rank's stored chunks: a dictionary must be resident)
+  if ((rc = hmse_l4_minhash_dyn(data, data_cap, cuts_all, uniq_all, sig_all, state, cap, cfg, w.mh_ws, w.mh_bytes, stream)) != HMSE_OK) return rc;
+  if ((rc = hmse_l4_lsh_update_dyn(sig_all, band_keys, base_all, lsh_tables, lsh_slots, state, cap, cfg, stream)) != HMSE_OK) return rc;
+  // L1: dictionary DEFLATE of the new stored chunks (a dictionary may be any stored chunk of this rank's stream so far)
+  sb::prep_deflate_kernel<<<dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, stream>>>(uniq_all, base_all, state, w.sel_ids, w.sel_base, w.n_sel);
+  if ((rc = hmse_l1_deflate_dyn(data, data_cap, cuts_all, w.sel_ids, w.sel_base, w.n_sel, cap, state + SB_S_OLD, cfg, out, out_cap, w.out_off, w.kind,
+                                w.dfl_status, w.dfl_ws, w.dfl_bytes, stream)) != HMSE_OK) return rc;
+  uint32_t ab = (uint32_t)((cap + 255) / 256); if (ab > 1024) ab = 1024;
+  sb::commit_kernel<<<dim3(ab), dim3(256), 0, stream>>>(w.kind, w.out_off, cap, kind_all, stream_off_all, w.dfl_status, state);
+  sb::advance_kernel<<<dim3(1), dim3(1), 0, stream>>>(state, piece_bytes);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+static bool sb_piece_args_ok(uint64_t piece_bytes, uint64_t cap_bytes, uint32_t n_seg, const hmse_cfg* cfg) {
+  if (hmse_cfg_validate_impl(cfg) != 0) return false;
+  if ((cfg->layers & 15u) != 15u) return false;   // the streaming front end runs the full L1-L4 pipeline
+  if (cap_bytes == 0 || piece_bytes > cap_bytes) return false;
+  if (piece_bytes != 0 && n_seg == 0) return false;
+  if (n_seg > sb_n_seg(cap_bytes, cfg)) return false;
+  return true;
+}
+
+extern "C" int hmse_stream_piece_hash(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const uint64_t* seg_off,
+                                      uint32_t n_seg, const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks,
+                                      uint8_t* row, void* ws, size_t ws_bytes, void* stream_) {
+  if (!sb_piece_args_ok(piece_bytes, cap_bytes, n_seg, cfg)) return HMSE_EINVAL;
+  if (!data || !state || !cuts_all || !row || (piece_bytes && !seg_off)) return HMSE_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
+  return piece_hash(data, data_cap, piece_bytes, cap_bytes, seg_off, n_seg, cfg, state, cuts_all, max_chunks, row, w, stream);
+}
+
+extern "C" int hmse_stream_piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg,
+                                        uint64_t* state, const uint8_t* rows, uint32_t world, uint32_t rank, const uint64_t* cuts_all,
+                                        uint64_t* gidx, uint8_t* digests_g, uint64_t max_chunks_g, uint64_t* first_occ_g, uint32_t* refcount_g,
+                                        uint32_t* l3_table, uint64_t l3_slots, uint64_t* uniq_all, uint64_t max_unique, uint32_t* sig_all,
+                                        uint32_t* band_keys, int64_t* base_all, uint32_t* lsh_tables, uint64_t lsh_slots, uint8_t* kind_all,
+                                        uint64_t* stream_off_all, uint8_t* out, uint64_t out_cap, void* ws, size_t ws_bytes, void* stream_) {
+  if (!sb_piece_args_ok(piece_bytes, cap_bytes, piece_bytes ? 1u : 0u, cfg)) return HMSE_EINVAL;
+  if (!data || !state || !rows || !cuts_all || !digests_g || !first_occ_g || !refcount_g || !l3_table || !uniq_all || !sig_all || !band_keys ||
+      !base_all || !lsh_tables || !kind_all || !stream_off_all || !out || world == 0 || world > 256 || rank >= world)
+    return HMSE_EINVAL;
+  if (world > 1 && !gidx) return HMSE_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
+  return piece_encode(data, data_cap, piece_bytes, cap_bytes, cfg, state, rows, world, rank, cuts_all, gidx, digests_g, max_chunks_g, first_occ_g,
+                      refcount_g, l3_table, l3_slots, uniq_all, max_unique, sig_all, band_keys, base_all, lsh_tables, lsh_slots, kind_all,
+                      stream_off_all, out, out_cap, w, stream);
+}
+
+// one rank: both phases back to back, the exchange row (kept in the workspace) is the gathered array
 extern "C" int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batch_bytes, const uint64_t* seg_off, uint32_t n_seg,
                                  const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks, uint8_t* digests_all,
                                  uint64_t* first_occ, uint32_t* refcount, uint32_t* l3_table, uint64_t l3_slots, uint64_t* uniq_all,
                                  uint64_t max_unique, uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* lsh_tables,
                                  uint64_t lsh_slots, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out, uint64_t out_cap,
                                  void* ws, size_t ws_bytes, void* stream_) {
-  if (hmse_cfg_validate_impl(cfg) != 0) return HMSE_EINVAL;
+  if (batch_bytes == 0 || !sb_piece_args_ok(batch_bytes, batch_bytes, n_seg, cfg)) return HMSE_EINVAL;
   if (!data || !seg_off || !state || !cuts_all || !digests_all || !first_occ || !refcount || !l3_table || !uniq_all || !sig_all || !band_keys ||
-      !base_all || !lsh_tables || !kind_all || !stream_off_all || !out || batch_bytes == 0 || n_seg == 0)
+      !base_all || !lsh_tables || !kind_all || !stream_off_all || !out)
     return HMSE_EINVAL;
-  if ((cfg->layers & 15u) != 15u) return HMSE_EINVAL;   // the streaming front end runs the full L1-L4 pipeline
   hipStream_t stream = (hipStream_t)stream_;
   (void)hipGetLastError();
-  sb::Ws w = sb_carve(ws, batch_bytes, n_seg, cfg);
+  const sb::Ws w = sb_carve(ws, batch_bytes, cfg);
   if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
-  const uint64_t cap = sb_cap_chunks(batch_bytes, n_seg, cfg);
-  int rc;
-  // L2 on the batch's bytes (data + state[SB_OFF], read on the device)
-  if ((rc = hmse_l2_cdc_impl(data, state + SB_OFF, batch_bytes, seg_off, n_seg, cfg, w.cuts_local, cap + 1, w.n_cuts, w.l2_status, w.l2_ws,
-                             w.l2_bytes, stream)) != HMSE_OK) return rc;
-  uint32_t ab = (uint32_t)((cap + 255) / 256); if (ab > 1024) ab = 1024;
-  sb::append_cuts_kernel<<<dim3(ab), dim3(256), 0, stream>>>(w.cuts_local, w.n_cuts, cuts_all, state, max_chunks);
-  // L3: digests of the new chunks, persistent index
-  if ((rc = hmse_l3_sha256_dyn(data, data_cap, cuts_all, digests_all, state, cap, w.sha_ws, w.sha_bytes, stream)) != HMSE_OK) return rc;
-  if ((rc = hmse_l3_index_update_dyn(digests_all, first_occ, refcount, l3_table, l3_slots, state, cap, stream)) != HMSE_OK) return rc;
-  sb::select_uniq_kernel<<<dim3(1), dim3(1024), 0, stream>>>(first_occ, uniq_all, state, max_unique);
-  // L4: signatures of the new stored chunks, persistent band tables
-  if ((rc = hmse_l4_minhash_dyn(data, data_cap, cuts_all, uniq_all, sig_all, state, cap, cfg, w.mh_ws, w.mh_bytes, stream)) != HMSE_OK) return rc;
-  if ((rc = hmse_l4_lsh_update_dyn(sig_all, band_keys, base_all, lsh_tables, lsh_slots, state, cap, cfg, stream)) != HMSE_OK) return rc;
-  // L1: dictionary DEFLATE of the new stored chunks (a dictionary may be any stored chunk of the stream so far)
-  sb::prep_deflate_kernel<<<dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, stream>>>(uniq_all, base_all, state, w.sel_ids, w.sel_base, w.n_sel);
-  if ((rc = hmse_l1_deflate_dyn(data, data_cap, cuts_all, w.sel_ids, w.sel_base, w.n_sel, cap, state + SB_S_OLD, cfg, out, out_cap, w.out_off, w.kind,
-                                w.dfl_status, w.dfl_ws, w.dfl_bytes, stream)) != HMSE_OK) return rc;
-  sb::commit_kernel<<<dim3(ab), dim3(256), 0, stream>>>(w.kind, w.out_off, cap, kind_all, stream_off_all, w.dfl_status, w.l2_status, state);
-  sb::advance_kernel<<<dim3(1), dim3(1), 0, stream>>>(state, batch_bytes);
-  HMSE_LAUNCH_CHECK();
-  return HMSE_OK;
+  int rc = piece_hash(data, data_cap, batch_bytes, batch_bytes, seg_off, n_seg, cfg, state, cuts_all, max_chunks, w.row, w, stream);
+  if (rc != HMSE_OK) return rc;
+  return piece_encode(data, data_cap, batch_bytes, batch_bytes, cfg, state, w.row, 1u, 0u, cuts_all, nullptr, digests_all, max_chunks, first_occ, refcount,
+                      l3_table, l3_slots, uniq_all, max_unique, sig_all, band_keys, base_all, lsh_tables, lsh_slots, kind_all, stream_off_all, out,
+                      out_cap, w, stream);
 }

@@ -383,3 +383,46 @@ def stream_batch(data: torch.Tensor, batch_bytes: int, seg_off: torch.Tensor, cf
                                          _ptr(lsh_tables), lsh_tables.shape[1], _ptr(kind_all), _ptr(stream_off_all), _ptr(out), out.numel(),
                                          ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_stream_batch")
+
+
+def stream_row_bytes(cap_bytes: int, cfg: IngestConfig) -> int:
+    c = cfg.to_c()
+    return int(_lib.hip_lib().hmse_stream_row_bytes(int(cap_bytes), C.byref(c)))
+
+
+def stream_piece_hash(data: torch.Tensor, piece_bytes: int, cap_bytes: int, seg_off: torch.Tensor | None, cfg: IngestConfig, state: torch.Tensor,
+                      cuts_all: torch.Tensor, max_chunks: int, row: torch.Tensor, ws: torch.Tensor) -> None:
+    """hmse_stream_piece_hash: phase A of a multi-rank stream's batch (L2 + L3 hash of this rank's piece -> its exchange row).
+    README.md:1519-1540."""
+    for t, nm in ((data, "data"), (state, "state"), (cuts_all, "cuts"), (row, "row"), (ws, "ws")):
+        _require_gpu(t, nm)
+    if seg_off is not None:
+        _require_gpu(seg_off, "seg_off")
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_piece_hash(_ptr(data), data.numel(), int(piece_bytes), int(cap_bytes), _ptr(seg_off),
+                                              0 if seg_off is None else seg_off.numel() - 1, C.byref(c), _ptr(state), _ptr(cuts_all), int(max_chunks),
+                                              _ptr(row), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_piece_hash")
+
+
+def stream_piece_encode(data: torch.Tensor, piece_bytes: int, cap_bytes: int, cfg: IngestConfig, state: torch.Tensor, rows: torch.Tensor, world: int,
+                        rank: int, cuts_all: torch.Tensor, gidx: torch.Tensor | None, digests_g: torch.Tensor, max_chunks_g: int,
+                        first_occ_g: torch.Tensor, refcount_g: torch.Tensor, l3_table: torch.Tensor, uniq_all: torch.Tensor, max_unique: int,
+                        sig_all: torch.Tensor, band_keys: torch.Tensor, base_all: torch.Tensor, lsh_tables: torch.Tensor, kind_all: torch.Tensor,
+                        stream_off_all: torch.Tensor, out: torch.Tensor, ws: torch.Tensor) -> None:
+    """hmse_stream_piece_encode: phase B (gathered rows -> global index -> this rank's stored chunks -> L4 -> L1).  README.md:1538-1580."""
+    for t, nm in ((data, "data"), (state, "state"), (rows, "rows"), (cuts_all, "cuts"), (digests_g, "digests"), (first_occ_g, "first_occ"),
+                  (refcount_g, "refcount"), (l3_table, "l3_table"), (uniq_all, "uniq"), (sig_all, "sig"), (band_keys, "band_keys"), (base_all, "base"),
+                  (lsh_tables, "lsh_tables"), (kind_all, "kind"), (stream_off_all, "stream_off"), (out, "out"), (ws, "ws")):
+        _require_gpu(t, nm)
+    if gidx is not None:
+        _require_gpu(gidx, "gidx")
+    if rows.numel() != world * stream_row_bytes(cap_bytes, cfg):
+        raise HmseError(-1, "stream_piece_encode: rows must hold one exchange row per rank")
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_piece_encode(_ptr(data), data.numel(), int(piece_bytes), int(cap_bytes), C.byref(c), _ptr(state), _ptr(rows), int(world),
+                                                int(rank), _ptr(cuts_all), _ptr(gidx), _ptr(digests_g), int(max_chunks_g), _ptr(first_occ_g),
+                                                _ptr(refcount_g), _ptr(l3_table), l3_table.numel(), _ptr(uniq_all), int(max_unique), _ptr(sig_all),
+                                                _ptr(band_keys), _ptr(base_all), _ptr(lsh_tables), lsh_tables.shape[1], _ptr(kind_all),
+                                                _ptr(stream_off_all), _ptr(out), out.numel(), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_piece_encode")

@@ -43,7 +43,9 @@ def reconstruct_shard(res, verify: bool = True) -> torch.Tensor:
 
 
 def reconstruct_shards(results: list, verify: bool = True) -> list:
-    """Inverse of a sharded ingest whose records may use dictionaries stored on OTHER shards (ingest_shard(global_l4=True)):
+    """Inverse of a sharded ingest whose records may use dictionaries stored on OTHER shards (ingest_shard(global_l4=True)),
+    or of a multi-rank STREAM (stream_dist.DistStreamIngest: the ranks' chunks interleave in global order, `res.gidx` names
+    every local chunk's global index and a first occurrence may live on any rank):
     the stored records of all shards are inflated in ONE call, in global stored-chunk order (= rank order), so that a
     DELTA record's dictionary — named by its global stored-chunk index — is any earlier record; then every shard's chunks
     are laid out from the slots their first occurrences name.  Returns the shards' data tensors, in order."""
@@ -66,11 +68,15 @@ def reconstruct_shards(results: list, verify: bool = True) -> list:
     n_global = results[0].n_global
     slot_of_global = torch.full((n_global,), -1, dtype=torch.int64, device=dev)
     for r, ub in zip(results, u_bases):
-        slot_of_global[r.chunk_base + r.uniq_ids] = torch.arange(ub, ub + r.uniq_ids.numel(), dtype=torch.int64, device=dev)
+        g = getattr(r, "gidx", None)
+        own = g[r.uniq_ids] if g is not None else r.chunk_base + r.uniq_ids
+        slot_of_global[own] = torch.arange(ub, ub + r.uniq_ids.numel(), dtype=torch.int64, device=dev)
     out = []
     for r in results:
         n_chunks = r.cuts.numel() - 1
         fo = r.first_occ if r.first_occ is not None else torch.arange(r.chunk_base, r.chunk_base + n_chunks, dtype=torch.int64, device=dev)
+        if bool(((fo < 0) | (fo >= n_global)).any()):
+            raise ReadError("a first occurrence lies outside the global chunk range")
         slots = slot_of_global[fo]
         if bool((slots < 0).any()):
             raise ReadError("a first occurrence is not a stored chunk of any shard")

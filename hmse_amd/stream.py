@@ -184,8 +184,9 @@ class StreamIngest:
         """The ONE host read of the chain: counts after the batches enqueued so far."""
         st = self._state.tolist()
         if st[7]:
-            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bits 8.. DEFLATE "
-                             "(0x100 stream capacity, 0x200 workspace)")
+            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 exchange row, "
+                             "bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped "
+                             f"({st[0]} bytes / {st[1]} chunks are intact)")
         self.n_done, self.n_chunks, self.n_unique, self.stream_bytes = st[0], st[1], st[3], st[5]
 
     def _chain_call(self, n: int, seg_off: torch.Tensor, ws: torch.Tensor) -> None:
@@ -200,7 +201,7 @@ class StreamIngest:
             if self.n_chunks == 0:
                 ops.l3_index_update(self._digests, 0, 0, self._first_occ, self._refcount, self._l3_table)      # clears the table
                 ops.l4_lsh_update(self._sig, 0, 0, self.cfg, self._band_keys, self._base, self._lsh_tables)     # clears the tables
-            self._state.copy_(torch.tensor([off, self.n_chunks, 0, self.n_unique, 0, self.stream_bytes] + [0] * 10, dtype=torch.int64))
+            self._state.copy_(torch.tensor([off, self.n_chunks, 0, self.n_unique, 0, self.stream_bytes, 0, 0, self.n_chunks] + [0] * 7, dtype=torch.int64))
             self._state_dirty = False
         torch.cuda.current_stream().wait_event(copied)
         entry = self._graphs.get(n, 0)

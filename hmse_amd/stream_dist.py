@@ -1,0 +1,256 @@
+"""Multi-GPU streaming (BASELINE.json configs[4]: "4 x 10 GB mixed corpora streamed, 8 x MI355X, hipGraph-captured per-batch
+pipeline"; the reference's batch loop README.md:1519-1580 against ONE index, one process per GPU).
+
+Definition.  The stream arrives as GLOBAL BATCHES.  A batch is dealt to the ranks as contiguous runs of whole segments
+("pieces": rank 0 gets the first run, rank 1 the next, ...), so the concatenation of the pieces in (batch, rank) order IS the
+logical stream, and the global chunk order is (batch, rank, local index) — the natural order of that stream.  Per batch:
+
+  phase A   every rank: L2 FastCDC + L3 SHA-256 of ITS piece -> its exchange row {count, digests}       hmse_stream_piece_hash
+  exchange  ONE all-gather of the rows (fixed-size rows: no count round trip, capturable)                RCCL over xGMI
+  phase B   every rank: rows -> the global digest array in (batch, rank, local) order -> the same persistent L3 table on every
+            rank (order-independent first occurrences, hmse_l3_index_update's rule) -> ITS stored chunks -> L4 MinHash +
+            ITS persistent band tables -> L1 dictionary DEFLATE -> index tails, state advanced           hmse_stream_piece_encode
+
+Dedupe is therefore GLOBAL over the stream so far (a chunk is stored by the rank that holds its first occurrence in stream
+order); L4 bases and dictionaries are scoped to the rank (the dictionary bytes must be resident), exactly as in the sharded
+one-shot ingest (ingest.ingest_shard(distributed=True)) — which is the one-batch special case of this definition.  No host
+read happens between the stages; with graph=True phase A and phase B of a piece size are captured into two hipGraphs at their
+second use and replayed from then on (the collective stays an ordinary stream-ordered RCCL call between the two replays).
+
+`exchange(row) -> rows` replaces the collective: tests/ and ingest-on-one-GPU emulations drive several ranks in lock step
+(stream_shards_local).  The oracle of this definition is tests/test_gpu_stream_dist.py::oracle_stream_pipeline.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import LAYER_L1, LAYER_L2, LAYER_L3, LAYER_L4, IngestConfig
+from .ingest import ShardResult, shard_stats
+
+
+import os as _os
+_DEBUG_SYNC = _os.environ.get("HMSE_STREAM_DEBUG_SYNC") == "1"
+
+
+def deal_batch(batch_bytes: int, world: int, seg_size: int) -> list:
+    """Piece boundaries of a global batch of `batch_bytes`: contiguous runs of whole segments, rank r gets segments
+    [r S / R, (r + 1) S / R) of the batch's S segments (the last segment may be partial: only the stream's last batch)."""
+    n_seg = -(-batch_bytes // seg_size)
+    b = [min(batch_bytes, (r * n_seg // world) * seg_size) for r in range(world)] + [batch_bytes]
+    return b
+
+
+def all_gather_rows(row: torch.Tensor, world: int, group=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """THE collective of a multi-rank stream's batch: all-gather of the ranks' fixed-size exchange rows, in rank order.
+    RCCL over xGMI: device to device, stream-ordered, no host read (1 GiB pieces: 16.8 MB per rank and batch).  gloo (the CPU
+    tests and the one-GPU rehearsal): staged through host memory."""
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty(world * row.numel(), dtype=torch.uint8, device=row.device)
+    if dist.get_backend(group) == "gloo":
+        rows = torch.empty(world * row.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(rows, row.cpu(), group=group)
+        out.copy_(rows)
+    else:
+        dist.all_gather_into_tensor(out, row, group=group)
+    return out
+
+
+class DistStreamIngest:
+    """This rank's side of a stream sharded over `world` ranks.  Every rank pushes ITS piece of every global batch, in the
+    same order (a rank with no bytes in a batch pushes an empty tensor) — the per-batch exchange is a collective."""
+
+    def __init__(self, cfg: IngestConfig, capacity_bytes: int, piece_bytes: int, device, world: int, rank: int,
+                 max_chunks_global: int | None = None, max_chunks: int | None = None, stream_capacity: int | None = None,
+                 graph: bool = True, group=None, exchange=None):
+        if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
+            raise ValueError("DistStreamIngest runs the full L1-L4 pipeline")
+        if piece_bytes <= 0 or piece_bytes % cfg.seg_size:
+            raise ValueError("piece_bytes (the nominal piece size) must be a positive multiple of seg_size")
+        if not 0 <= rank < world <= 256:
+            raise ValueError("0 <= rank < world <= 256")
+        self.cfg, self.dev, self.world, self.rank, self.group = cfg, device, int(world), int(rank), group
+        self.cap_bytes = int(piece_bytes)
+        self.data = torch.empty(int(capacity_bytes), dtype=torch.uint8, device=device)
+        self.n_bytes = 0
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.pending: list[tuple[int, int, torch.cuda.Event]] = []
+        per = max(1, cfg.avg_size // 2)
+        self.max_chunks = int(max_chunks or (capacity_bytes // per + capacity_bytes // cfg.seg_size + 64))
+        self.max_chunks_g = int(max_chunks_global or self.max_chunks * world)
+        self.max_unique = min(self.max_chunks, 1 << 23)
+        mc, mg, mu = self.max_chunks, self.max_chunks_g, self.max_unique
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        # this rank's chunks
+        self._cuts = z(mc + 1, torch.int64)
+        self._gidx = z(mc, torch.int64)                       # local chunk -> global chunk index
+        self._uniq = z(mu, torch.int64)                       # local ids of the chunks this rank stores, ascending
+        self._sig = torch.empty((mu, cfg.n_hashes), dtype=torch.int32, device=device)
+        self._band_keys = z((mu, cfg.bands), torch.int32)
+        self._base = z(mu, torch.int64)
+        self._kind = z(mu, torch.uint8)
+        self._stream_off = z(mu + 1, torch.int64)
+        self._lsh_tables = torch.empty((cfg.bands, ops.l4_lsh_slots(mu)), dtype=torch.int32, device=device)
+        self._streams = torch.empty(int(stream_capacity or (capacity_bytes // 2 + (64 << 20))), dtype=torch.uint8, device=device)
+        # the global index: identical on every rank
+        self._digests_g = torch.empty((mg, 32), dtype=torch.uint8, device=device)
+        self._first_occ_g = z(mg, torch.int64)
+        self._refcount_g = z(mg, torch.int32)
+        self._l3_table = torch.empty(ops.l3_index_slots(mg), dtype=torch.int32, device=device)
+        ops.l3_index_update(self._digests_g, 0, 0, self._first_occ_g, self._refcount_g, self._l3_table)     # clears the table
+        ops.l4_lsh_update(self._sig, 0, 0, cfg, self._band_keys, self._base, self._lsh_tables)               # clears the tables
+        self._state = torch.zeros(16, dtype=torch.int64, device=device)
+        self._ws = torch.empty(ops.stream_batch_workspace_bytes(self.cap_bytes, cfg), dtype=torch.uint8, device=device)
+        self.row_bytes = ops.stream_row_bytes(self.cap_bytes, cfg)
+        self._row = torch.zeros(self.row_bytes, dtype=torch.uint8, device=device)
+        self._rows = torch.zeros(self.world * self.row_bytes, dtype=torch.uint8, device=device)
+        self.graph = bool(graph)
+        self._graphs: dict[int, list] = {}      # piece bytes -> [seg_off, graph A or None, graph B or None, uses]
+        self._exchange = exchange
+        self.n_batches = 0
+
+    # ------------------------------------------------------------------ the exchange step
+    def _all_gather(self, row: torch.Tensor) -> torch.Tensor:
+        if self._exchange is not None:
+            return self._exchange(row)
+        if self.world == 1:
+            return row
+        return all_gather_rows(row, self.world, self.group, out=self._rows)
+
+    # ------------------------------------------------------------------ the two phases (enqueue only)
+    def _entry(self, n: int) -> list:
+        e = self._graphs.get(n)
+        if e is None:
+            e = [ops.segment_offsets(n, self.cfg.seg_size, self.dev) if n else None, None, None, 0]
+            self._graphs[n] = e
+        return e
+
+    def _call_hash(self, n: int, seg_off) -> None:
+        ops.stream_piece_hash(self.data, n, self.cap_bytes, seg_off, self.cfg, self._state, self._cuts, self.max_chunks, self._row, self._ws)
+
+    def _call_encode(self, n: int, rows: torch.Tensor) -> None:
+        ops.stream_piece_encode(self.data, n, self.cap_bytes, self.cfg, self._state, rows, self.world, self.rank, self._cuts, self._gidx,
+                                self._digests_g, self.max_chunks_g, self._first_occ_g, self._refcount_g, self._l3_table, self._uniq,
+                                self.max_unique, self._sig, self._band_keys, self._base, self._lsh_tables, self._kind, self._stream_off,
+                                self._streams, self._ws)
+
+    def _run(self, which: int, n: int, fn) -> None:
+        """First use of a piece size: plain enqueue (also sets the kernels' attributes before any capture); second use:
+        capture into a hipGraph; from then on: replay."""
+        e = self._entry(n)
+        if _DEBUG_SYNC:     # HMSE_STREAM_DEBUG_SYNC=1: localise a device fault to (rank, batch, phase) — diagnostics only
+            import sys
+            torch.cuda.synchronize()
+            cap = (self.row_bytes - 32) // 32
+            o = (((cap + 1) * 8 + 255) // 256) * 256
+            l2o = o + 512 + 2 * ((cap * 8 + 255) // 256 * 256) + 256 + (((cap + 1) * 8 + 255) // 256) * 256 + ((cap + 255) // 256) * 256 + 256 + ((self.row_bytes + 255) // 256) * 256
+            print(f"[stream_dist] rank {self.rank} batch {self.n_batches} phase {'AB'[which - 1]} n={n} state={self._state.tolist()[:11]} n_cuts={self._ws[o:o + 8].view(torch.int64).item()} "
+                  f"l2_status={self._ws[o + 256:o + 260].view(torch.int32).item()} l2hdr={self._ws[l2o:l2o + 32].view(torch.int64).tolist()}", file=sys.stderr, flush=True)
+        if not self.graph or e[3] < 1:
+            fn()
+        else:
+            if e[which] is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                e[which] = g
+            e[which].replay()
+
+    def hash_piece(self, n: int) -> torch.Tensor:
+        """Phase A for the next piece (its bytes are at data[state.off ..)): returns this rank's exchange row."""
+        e = self._entry(n)
+        self._run(1, n, lambda: self._call_hash(n, e[0]))
+        return self._row
+
+    def encode_piece(self, n: int, rows: torch.Tensor) -> None:
+        """Phase B: `rows` = the rows of all ranks in rank order (a tensor whose address is stable across batches when graphs are on)."""
+        if rows.data_ptr() != self._rows.data_ptr() and not (self.world == 1 and rows.data_ptr() == self._row.data_ptr()):
+            self._rows.copy_(rows.reshape(-1))
+            rows = self._rows
+        self._run(2, n, lambda: self._call_encode(n, rows))
+        self._entry(n)[3] += 1
+        self.n_batches += 1
+
+    # ------------------------------------------------------------------ feeding
+    def push(self, host_piece: torch.Tensor) -> None:
+        """Issue the host -> HBM copy of this rank's piece of the next global batch, then process the piece whose copy was
+        issued by the previous push (its kernels overlap this copy).  COLLECTIVE: every rank pushes once per global batch."""
+        n = host_piece.numel()
+        if n > self.cap_bytes:
+            raise ValueError("a piece may not exceed the stream's nominal piece size")
+        if self.n_bytes % self.cfg.seg_size:
+            raise ValueError("only a rank's last piece may end inside a segment")
+        if self.n_bytes + n > self.data.numel():
+            raise ValueError("stream capacity exceeded")
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.copy_stream):
+            if n:
+                self.data[self.n_bytes: self.n_bytes + n].copy_(host_piece, non_blocking=True)
+            ev.record(self.copy_stream)
+        while self.pending:
+            self._process(*self.pending.pop(0))
+        self.pending.append((self.n_bytes, n, ev))
+        self.n_bytes += n
+
+    def _process(self, off: int, n: int, copied: torch.cuda.Event) -> None:
+        torch.cuda.current_stream().wait_event(copied)
+        row = self.hash_piece(n)
+        rows = self._all_gather(row)
+        self.encode_piece(n, rows)
+
+    # ------------------------------------------------------------------ results
+    def read_state(self, check: bool = True) -> list:
+        st = self._state.tolist()
+        status = st[7]
+        if check and self.world > 1 and self._exchange is None:
+            # a failed rank must fail the whole stream: its chunks are missing from every rank's index
+            import torch.distributed as dist
+            t = torch.tensor([status], dtype=torch.int64, device="cpu" if dist.get_backend(self.group) == "gloo" else self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            status = max(status, int(t.item()))
+        if check and status:
+            raise ValueError(f"streaming chain status {status:#x} on some rank: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 "
+                             "exchange row, bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped")
+        return st
+
+    def finish(self, check: bool = True) -> ShardResult:
+        while self.pending:
+            self._process(*self.pending.pop(0))
+        st = self.read_state(check)
+        n_done, n_chunks, n_unique, s_bytes, n_global = st[0], st[1], st[3], st[5], st[8]
+        gidx = self._gidx[:n_chunks]
+        res = ShardResult(n_done, self._cuts[: n_chunks + 1], self._digests_g[gidx], 0, n_global, self._first_occ_g[gidx], self._refcount_g[gidx],
+                          self._uniq[:n_unique], self._sig[:n_unique], self._band_keys[:n_unique], self._base[:n_unique], self._streams[:s_bytes],
+                          self._stream_off[: n_unique + 1], self._kind[:n_unique])
+        res.gidx = gidx
+        res.stats = shard_stats(res)
+        return res
+
+
+def stream_shards_local(batches: list, cfg: IngestConfig, world: int, device, piece_bytes: int | None = None, graph: bool = True,
+                        **kw) -> list:
+    """A `world`-rank stream with every rank on THIS GPU, in lock step: phase A of every rank, the rows concatenated as the
+    all-gather would deliver them, phase B of every rank — per global batch.  `batches`: host uint8 tensors (the global
+    batches, whole segments except the last).  Each result is what the rank would hold after DistStreamIngest.finish()."""
+    seg = cfg.seg_size
+    bounds = [deal_batch(b.numel(), world, seg) for b in batches]
+    pb = piece_bytes or max(max(bd[r + 1] - bd[r] for r in range(world)) for bd in bounds)
+    pb = -(-pb // seg) * seg
+    local_total = [sum(bd[r + 1] - bd[r] for bd in bounds) for r in range(world)]
+    ranks = [DistStreamIngest(cfg, max(local_total[r], 1), pb, device, world, r, graph=graph, exchange=lambda row: row, **kw) for r in range(world)]
+    rows = torch.zeros(world * ranks[0].row_bytes, dtype=torch.uint8, device=device)
+    for b, bd in zip(batches, bounds):
+        ns = []
+        for r, s in enumerate(ranks):
+            n = bd[r + 1] - bd[r]
+            if n:
+                s.data[s.n_bytes: s.n_bytes + n].copy_(b[bd[r]: bd[r + 1]])
+            ns.append(n)
+            row = s.hash_piece(n)
+            rows[r * s.row_bytes: (r + 1) * s.row_bytes].copy_(row)
+        for n, s in zip(ns, ranks):
+            s.encode_piece(n, rows)
+            s.n_bytes += n
+    return [s.finish() for s in ranks]

@@ -268,12 +268,15 @@ int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* 
  * L3 lookup/insert -> L4 probe -> delta or full).  The batch's bytes are already at data[state[0] .. + batch_bytes); every
  * stage takes its ranges from `state` (DEVICE u64[16]: [0] byte offset, [1] chunks so far, [2] chunks of this batch (out),
  * [3] stored chunks so far, [4] stored chunks of this batch (out), [5] stream bytes so far, [6] stream bytes of this batch
- * (out), [7] sticky status: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2 status, bits 8.. DEFLATE status), grids
- * and workspace are sized for batch_bytes / min_size chunks, and the call ends by advancing [0], [1], [3], [5] — so the chain
- * can be captured into a hipGraph once per batch size and replayed for every batch.  Appends to the per-chunk arrays of the
- * stream (cuts_all, digests_all, first_occ, refcount, uniq_all, sig_all, band_keys, base_all, kind_all, stream_off_all), to the
- * persistent L3 table / L4 band tables, and writes the batch's DEFLATE streams to out[state[5] ..).  seg_off DEVICE
- * u64[n_seg+1]: batch-local segment offsets.  ws: hmse_stream_batch_workspace_bytes(batch_bytes, cfg).
+ * (out), [7] sticky status: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2 status, bit3 malformed exchange row,
+ * bits 8.. DEFLATE status; [8] chunks of ALL ranks so far (== [1] for one rank), [9] chunks of all ranks in this batch (out),
+ * [10] global index of this rank's first chunk of the batch (out)), grids and workspace are sized for batch_bytes / min_size
+ * chunks, and the call ends by advancing [0], [1], [3], [5], [8] — so the chain can be captured into a hipGraph once per batch
+ * size and replayed for every batch.  Once [7] is non-zero the failing batch has been dropped and every later call is a no-op
+ * (counters frozen at the last good batch): nothing is ever appended to an index that is no longer consistent.  Appends to the
+ * per-chunk arrays of the stream (cuts_all, digests_all, first_occ, refcount, uniq_all, sig_all, band_keys, base_all, kind_all,
+ * stream_off_all), to the persistent L3 table / L4 band tables, and writes the batch's DEFLATE streams to out[state[5] ..).
+ * seg_off DEVICE u64[n_seg+1]: batch-local segment offsets.  ws: hmse_stream_batch_workspace_bytes(batch_bytes, cfg).
  */
 uint64_t hmse_stream_batch_workspace_bytes(uint64_t batch_bytes, const hmse_cfg* cfg);
 int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batch_bytes, const uint64_t* seg_off, uint32_t n_seg,
@@ -282,6 +285,40 @@ int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batch_bytes, co
                       uint64_t max_unique, uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* lsh_tables,
                       uint64_t lsh_slots, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out, uint64_t out_cap,
                       void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * The same chain for a stream that is sharded over several ranks (one process per GPU; BASELINE.json configs[4] "4 x 10 GB
+ * streamed, 8 x MI355X, hipGraph-captured per-batch pipeline").  A global batch is dealt to the ranks as contiguous runs of
+ * whole segments ("pieces", rank order = stream order inside the batch), so the GLOBAL CHUNK ORDER is (batch, rank, local
+ * index) and equals the natural order of the concatenated stream.  The reference's per-chunk "L3 lookup -> found: pointer /
+ * new: insert" (README.md:1538-1551) against ONE index becomes, per batch: phase A on every rank, ONE all-gather of the ranks'
+ * exchange rows (RCCL over xGMI; the caller's job — this library never communicates), phase B on every rank.  Every rank
+ * keeps a replica of the global digest array and of the L3 table and applies the same order-independent first-occurrence rule
+ * to the same rows, so dedupe is that of the one-rank stream; L4 bases and dictionaries are scoped to the rank (the bytes
+ * must be resident), exactly as in the sharded one-shot ingest.
+ *   cap_bytes    the NOMINAL piece size of the stream (>= every piece_bytes): it alone sizes rows, grids and the workspace, so
+ *                that every rank's row has the same layout whatever its piece holds (a rank may get 0 bytes in the last batch)
+ *   row          DEVICE u8[hmse_stream_row_bytes(cap_bytes)]: {u64 n_chunks, 24 B zero, n_chunks x 32 B digests, unused tail}
+ *   rows         DEVICE u8[world][row bytes]: the all-gathered rows in rank order (world == 1: rows == row)
+ *   cuts_all / uniq_all / sig_all / band_keys / base_all / kind_all / stream_off_all / out / lsh_tables: THIS RANK's arrays
+ *                (chunk ids are local); gidx DEVICE u64[max local chunks]: global index of every local chunk (out; may be
+ *                NULL when world == 1)
+ *   digests_g / first_occ_g / refcount_g / l3_table: the GLOBAL arrays (max_chunks_g entries), identical on every rank
+ *   state        as hmse_stream_batch: [1]..[6] count this rank's chunks / stored chunks / stream bytes, [8]..[10] the global ones
+ *   ws           hmse_stream_batch_workspace_bytes(cap_bytes, cfg); both phases of a batch take the SAME workspace
+ * Both calls are stream-ordered and capturable; hmse_stream_batch == hash + encode with world 1 on the row in its workspace.
+ */
+uint64_t hmse_stream_row_bytes(uint64_t cap_bytes, const hmse_cfg* cfg);
+int hmse_stream_piece_hash(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const uint64_t* seg_off,
+                           uint32_t n_seg, const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks,
+                           uint8_t* row, void* ws, size_t ws_bytes, void* stream);
+int hmse_stream_piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg,
+                             uint64_t* state, const uint8_t* rows, uint32_t world, uint32_t rank, const uint64_t* cuts_all,
+                             uint64_t* gidx, uint8_t* digests_g, uint64_t max_chunks_g, uint64_t* first_occ_g,
+                             uint32_t* refcount_g, uint32_t* l3_table, uint64_t l3_slots, uint64_t* uniq_all,
+                             uint64_t max_unique, uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all,
+                             uint32_t* lsh_tables, uint64_t lsh_slots, uint8_t* kind_all, uint64_t* stream_off_all,
+                             uint8_t* out, uint64_t out_cap, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Chunk manifest — the packed on-disk records, written on the GPU (README.md:1263-1270 ChunkIndex 40 B, 2182-2189

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hmse_amd import IngestConfig, _lib, corpus, ops
 v=sys.argv[1]
 if v!="base": _lib.HIP_LIB_PATH=_lib.HIP_LIB_PATH.replace("libhmse_hip.so", f"libhmse_hip_l2_{v}.so")

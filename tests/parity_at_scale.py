@@ -1,5 +1,5 @@
 """One-off parity run at a size the CPU oracle needs minutes for: every output of ingest_shard against the oracle pipeline.
-python tools/parity_at_scale.py [MiB] [profile]   (the committed tests do the same at <= 5 MiB)"""
+python tests/parity_at_scale.py [MiB] [profile]   (the committed tests do the same at <= 5 MiB)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

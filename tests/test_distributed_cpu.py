@@ -110,3 +110,77 @@ def test_cross_rank_base_fetch_three_ranks():
         assert lens.tolist() == [len(w) for w in want]
         assert np.array_equal(payload, np.concatenate(want) if want else np.zeros(0, np.uint8))
     assert ub[3] == len(stored)
+
+
+def _row_worker(rank, world, port, rows_by_batch, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hmse_amd import stream_dist
+    got = []
+    out = None
+    for rows in rows_by_batch:                    # one collective per global batch, the same buffer re-used (as the captured chain does)
+        out = stream_dist.all_gather_rows(torch.from_numpy(rows[rank]), world, out=out)
+        got.append(out.numpy().copy())
+    out_q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stream_row_exchange_and_global_order_two_ranks(orc):
+    """The per-batch exchange of a multi-rank stream (hmse_amd/stream_dist.py): every rank contributes a FIXED-SIZE row
+    {u64 count, 24 B pad, digests} per global batch, one all-gather delivers the rows in rank order to everybody; the global
+    chunk order (batch, rank, local) read off the rows is the natural order of the logical stream, so the first-occurrence rule
+    over it equals the rule over one ingest of the whole stream.  Includes a batch in which a rank has nothing."""
+    from hmse_amd import corpus
+    world, seg, B = 2, 1 << 20, 4 << 20
+    data = corpus.wiki_synth(9 << 20, seed=42)
+    data[(5 << 20) + 777: (6 << 20)] = data[777: (1 << 20)]                     # duplicates across batches and ranks
+    data[(1 << 20): (1 << 20) + 300000] = data[(3 << 20): (3 << 20) + 300000]    # a LATER rank's piece holds the first occurrence
+    cfg = orc.default_cfg(seg_size=seg)
+    cap = (B // world) // cfg.min_size + (B // world) // seg + 2                 # hmse_stream_row_bytes' chunk capacity
+    row_bytes = 32 + 32 * cap
+    rows_by_batch, stream_digests = [], []
+    for b0 in range(0, data.size, B):
+        n = min(B, data.size - b0)
+        s = -(-n // seg)
+        bd = [min(n, (r * s // world) * seg) for r in range(world)] + [n]
+        rows = []
+        for r in range(world):
+            piece = data[b0 + bd[r]: b0 + bd[r + 1]]
+            row = np.zeros(row_bytes, np.uint8)
+            if piece.size:
+                dg = orc.sha256_chunks(piece, orc.cdc(piece, cfg))
+                row[:8] = np.frombuffer(np.uint64(len(dg)).tobytes(), np.uint8)
+                row[32: 32 + dg.size] = dg.reshape(-1)
+                stream_digests.append(dg)
+            rows.append(row)
+        rows_by_batch.append(rows)
+    assert int(np.frombuffer(rows_by_batch[-1][0][:8].tobytes(), np.uint64)[0]) == 0     # the ragged last batch: rank 0 has nothing
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, rows_by_batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    glob = []
+    for rank, per_batch in got:
+        mine = []
+        for b, allrows in enumerate(per_batch):
+            assert np.array_equal(allrows, np.concatenate(rows_by_batch[b]))   # rank order, identical on every rank
+            for r in range(world):
+                row = allrows[r * row_bytes: (r + 1) * row_bytes]
+                c = int(np.frombuffer(row[:8].tobytes(), np.uint64)[0])
+                mine.append(row[32: 32 + 32 * c].reshape(c, 32))
+        glob.append(np.concatenate(mine))
+    assert np.array_equal(glob[0], glob[1]) and np.array_equal(glob[0], np.concatenate(stream_digests))
+    # (batch, rank, local) order == the natural order of the stream: same first occurrences as one ingest of the whole
+    whole = orc.sha256_chunks(data, orc.cdc(data, cfg))
+    assert np.array_equal(glob[0], whole)
+    fo, rc = orc.dedup(glob[0])
+    fo1, rc1 = orc.dedup(whole)
+    assert np.array_equal(fo, fo1) and np.array_equal(rc, rc1) and (fo != np.arange(len(fo))).sum() > 100

@@ -1,0 +1,194 @@
+"""GPU: multi-rank streaming (BASELINE.json configs[4]; hmse_amd/stream_dist.py) on ONE GPU — the ranks run in lock step, the
+exchange is the concatenation the all-gather would deliver — against the CPU oracle of the same definition:
+global batches dealt to the ranks as contiguous segment runs, global chunk order (batch, rank, local), dedupe global over
+that order, L4 bases and dictionaries scoped to the rank.  Plus the capacity paths of the device-count chain: a batch that
+does not fit sets the sticky status and is dropped — no fault, no write out of bounds."""
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("cuts", "digests", "first_occ", "refcount", "uniq_ids", "sig", "band_keys", "base", "kind", "stream_off", "streams")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _dataset():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from hmse_amd import corpus
+    a = corpus.wiki_synth(4 << 20, seed=42)
+    v = variants_dataset(a)
+    return np.concatenate([a, v, corpus.wiki_synth((12 << 20) - a.size - v.size, seed=7), a[: (1 << 20) + 12345]])
+
+
+def deal(batch_bytes, world, seg):
+    """The dealing rule, restated: rank r gets segments [r S / R, (r + 1) S / R) of the batch's S segments."""
+    s = -(-batch_bytes // seg)
+    return [min(batch_bytes, (r * s // world) * seg) for r in range(world)] + [batch_bytes]
+
+
+def oracle_stream_pipeline(orc, data, cfg, world, batch_bytes):
+    """CPU restatement of a `world`-rank stream (README.md:1519-1580 against one index, sharded): per global batch every
+    rank chunks and hashes its piece; the digests of all pieces join ONE index in (batch, rank, local) order; a chunk is stored
+    by the rank holding its first occurrence; MinHash/LSH/dictionary DEFLATE per rank over ITS stored chunks in arrival order."""
+    oc = orc.default_cfg(**asdict(cfg))
+    seg = cfg.seg_size
+    pieces = [[] for _ in range(world)]       # per rank: (lo, hi) byte ranges of the logical stream
+    order = []                                # (rank, lo, hi) in global order
+    for b0 in range(0, data.size, batch_bytes):
+        n = min(batch_bytes, data.size - b0)
+        bd = deal(n, world, seg)
+        for r in range(world):
+            if bd[r + 1] > bd[r]:
+                pieces[r].append((b0 + bd[r], b0 + bd[r + 1])); order.append((r, b0 + bd[r], b0 + bd[r + 1]))
+    local = [np.concatenate([data[a:b] for a, b in p]) if p else np.zeros(0, np.uint8) for p in pieces]
+    cuts = [[np.uint64(0)] for _ in range(world)]
+    gidx = [[] for _ in range(world)]
+    dg_all, g, loc_off = [], 0, [0] * world
+    for r, a, b in order:
+        c = orc.cdc(data[a:b], oc)
+        dg_all.append(orc.sha256_chunks(data[a:b], c))
+        cuts[r] += list(c[1:] + np.uint64(loc_off[r]))
+        gidx[r] += list(range(g, g + len(c) - 1))
+        g += len(c) - 1; loc_off[r] += b - a
+    dg_all = np.concatenate(dg_all)
+    fo, rc = orc.dedup(dg_all)
+    out = []
+    for r in range(world):
+        cr = np.array(cuts[r], np.uint64); gi = np.array(gidx[r], np.int64)
+        uniq = np.nonzero(fo[gi] == gi.astype(np.uint64))[0].astype(np.uint64) if len(gi) else np.zeros(0, np.uint64)
+        sig = orc.minhash_chunks(local[r], cr, oc, uniq)
+        keys, base = orc.lsh(sig, oc)
+        streams, off, kind = orc.deflate_chunks(local[r], cr, oc, uniq, base)
+        out.append(dict(data=local[r], cuts=cr, gidx=gi, digests=dg_all[gi], first_occ=fo[gi], refcount=rc[gi], uniq_ids=uniq, sig=sig,
+                        band_keys=keys, base=base, kind=kind, stream_off=off, streams=streams, n_global=g))
+    return out
+
+
+def _same(res, want, tag):
+    for name in NAMES + ("gidx",):
+        got = getattr(res, name).cpu().numpy()
+        w = want[name]
+        if name in ("sig", "band_keys"):
+            got = got.view(np.uint32)
+        assert np.array_equal(got.astype(w.dtype) if got.dtype != w.dtype else got, w), (tag, name)
+    assert res.n_global == want["n_global"], tag
+
+
+@pytest.mark.parametrize("world,graph", [(2, True), (3, True), (3, False)])
+def test_multi_rank_stream_equals_oracle(orc, dev, world, graph):
+    import torch
+    from hmse_amd import IngestConfig, read, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset().copy()
+    # batch 1's first pieces repeat bytes of batch 0's LAST piece: first occurrences on another rank — one with a higher rank number
+    data[(4 << 20) + 100000: (4 << 20) + 100000 + 1200000] = data[(2 << 20) + 50000: (2 << 20) + 50000 + 1200000]
+    B = 4 << 20                                                    # 3 full batches + a ragged one (a rank gets nothing in it when world == 3)
+    want = oracle_stream_pipeline(orc, data, cfg, world, B)
+    batches = [torch.from_numpy(data[a: a + B].copy()) for a in range(0, data.size, B)]
+    res = stream_dist.stream_shards_local(batches, cfg, world, dev, graph=graph)
+    for r in range(world):
+        _same(res[r], want[r], (world, graph, r))
+    # pointers and dictionaries cross batches; first occurrences live on other ranks, earlier AND later ones
+    n_other = 0
+    for r in range(world):
+        own = np.isin(want[r]["first_occ"], want[r]["gidx"].astype(np.uint64))
+        n_other += int((~own).sum())
+    assert sum(int((res[r].kind == 2).sum()) for r in range(world)) > 5
+    assert n_other > 50
+    # the read path over all ranks' records returns every rank's bytes
+    back = read.reconstruct_shards(res, verify=True)
+    for r in range(world):
+        assert np.array_equal(back[r].cpu().numpy(), want[r]["data"]), r
+
+
+def test_one_batch_is_the_sharded_one_shot_ingest_and_one_rank_is_the_single_rank_stream(dev):
+    import torch
+    from hmse_amd import IngestConfig, ingest, stream, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()[: 9 << 20]
+    # (a) ONE global batch over 2 ranks == ingest_shards_local over the same two contiguous segment runs
+    bd = stream_dist.deal_batch(data.size, 2, cfg.seg_size)
+    shards = [torch.from_numpy(data[bd[r]: bd[r + 1]]).to(dev) for r in range(2)]
+    one_shot = ingest.ingest_shards_local(shards, cfg)
+    res = stream_dist.stream_shards_local([torch.from_numpy(data)], cfg, 2, dev, graph=False)
+    for r in range(2):
+        for name in NAMES:
+            assert torch.equal(getattr(res[r], name), getattr(one_shot[r], name)), (r, name)
+        assert torch.equal(res[r].gidx, torch.arange(one_shot[r].chunk_base, one_shot[r].chunk_base + res[r].gidx.numel(), device=dev))
+    # (b) ONE rank == the single-rank captured chain == one ingest of the whole stream
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    B = 2 << 20
+    batches = [torch.from_numpy(data[a: a + B].copy()) for a in range(0, data.size, B)]
+    (r1,) = stream_dist.stream_shards_local(batches, cfg, 1, dev, graph=True)
+    st = stream.StreamIngest(cfg, data.size, dev, graph=True)
+    for b in batches:
+        st.push(b)
+    r0 = st.finish()
+    for name in NAMES:
+        assert torch.equal(getattr(r1, name), getattr(whole, name)), name
+        assert torch.equal(getattr(r0, name), getattr(whole, name)), name
+
+
+def test_graphs_are_captured_once_per_piece_size(dev):
+    import torch
+    from hmse_amd import IngestConfig, corpus, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(8 << 20, seed=3)
+    s = stream_dist.DistStreamIngest(cfg, data.size, 2 << 20, dev, 1, 0, graph=True)
+    for a in range(0, data.size, 2 << 20):
+        s.push(torch.from_numpy(data[a: a + (2 << 20)].copy()).pin_memory())
+    res = s.finish()
+    e = s._graphs[2 << 20]
+    assert e[1] is not None and e[2] is not None and e[3] == 4      # eager once, captured at the second use, replayed after
+    assert int(res.cuts[-1]) == data.size and res.n_global == res.cuts.numel() - 1
+
+
+@pytest.mark.parametrize("which", ["chunks", "stored", "streams", "global"])
+def test_capacity_overflow_sets_the_sticky_status_and_drops_the_batch(dev, which):
+    """The device-count chain has no host in the loop to refuse a batch: a batch that does not fit (chunk arrays, stored-chunk
+    arrays, stream bytes, the global index of a multi-rank stream) must set state[7], be dropped as a whole, and turn every
+    later batch into a no-op — never write out of bounds (ADVICE r2 stream_batch.hip:85)."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest, stream, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(6 << 20, seed=5)
+    B = 2 << 20
+    first = ingest.ingest_shard(torch.from_numpy(data[:B]).to(dev), cfg)
+    n1, u1, s1 = first.cuts.numel() - 1, first.uniq_ids.numel(), first.streams.numel()
+    kw = {"chunks": dict(max_chunks=n1 + 10), "stored": dict(max_chunks=4 * n1), "streams": dict(stream_capacity=s1 + 1000), "global": {}}[which]
+    if which == "global":
+        s = stream_dist.DistStreamIngest(cfg, data.size, B, dev, 1, 0, max_chunks_global=n1 + 10, graph=True)
+    else:
+        s = stream.StreamIngest(cfg, data.size, dev, graph=True, **kw)
+        if which == "stored":
+            s.max_unique = u1 + 10                                    # the chain takes the bound as an argument
+    guard = {}
+    if which != "global":                                             # canaries behind the arrays the dropped batch must not touch
+        for nm in ("_cuts", "_uniq", "_kind", "_stream_off"):
+            guard[nm] = getattr(s, nm).clone()
+    for a in range(0, data.size, B):
+        s.push(torch.from_numpy(data[a: a + B].copy()))
+    with pytest.raises(ValueError, match="status"):
+        s.finish()
+    st = s._state.tolist()
+    want_bit = {"chunks": 1, "stored": 2, "streams": 0x100, "global": 1}[which]
+    assert st[7] & want_bit, hex(st[7])
+    # the first batch is intact, the counters are frozen there, nothing of the failed batches was committed
+    assert st[0] == B and st[1] == n1 and st[3] == u1 and st[5] == s1 and st[8] == n1
+    if which != "global":
+        assert torch.equal(s._cuts[: n1 + 1], first.cuts) and torch.equal(s._uniq[:u1], first.uniq_ids)
+        assert torch.equal(s._streams[:s1], first.streams) and torch.equal(s._kind[:u1], first.kind)
+        if which == "chunks":
+            assert torch.equal(s._cuts[n1 + 1:], guard["_cuts"][n1 + 1:])          # not one cut of the dropped batch was written
+        if which == "stored":
+            assert torch.equal(s._uniq[s.max_unique:], guard["_uniq"][s.max_unique:])
