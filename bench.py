@@ -31,6 +31,9 @@ STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel
 # match kernels: slots 8..13 = plain jobs of a size class, 18..23 = its dictionary jobs (last template argument)
 STAGE_NAMES.update({slot: f"l1_deflate_kernel<{args},false>" for slot, args in _CLS.items()})
 STAGE_NAMES.update({slot + 10: f"l1_deflate_kernel<{args},true>" for slot, args in _CLS.items()})
+# second pass (rule 7 of the encoder definition): FULL records of the chunks whose delta is larger than a fifth of the chunk
+STAGE_NAMES.update({slot + 16: f"l1_deflate_kernel<{args},false> [second pass]" for slot, args in _CLS.items()})
+STAGE_NAMES.update({30: "l1_encode_kernel<256,0,12288> [second pass]", 31: "l1_encode_kernel<256,12288,32768> [second pass]"})
 # what the SQ counters say about the kernels that can be "dominant" (profiles/r1/h_pmc_sq_counters_2GB.csv)
 VALU_NOTE = {"l4_minhash_kernel": "; SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 8 waves per SIMD = 1.1, i.e. the vector ALUs are "
                                   "saturated (9.25 instructions per (distinct shingle, seed) pair)"}
@@ -81,7 +84,8 @@ def _cpu_segment(args):
             delta = len(co.compress(ch) + co.flush())
         co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY)
         full = len(co.compress(ch) + co.flush())
-        stored += delta if b >= 0 and delta + 8 < full else full     # the delta rule of SURVEY.md D7
+        # rule 7 (README.md:1328, 2175): a delta of at most a fifth of the chunk is kept, a larger one iff it nets savings
+        stored += delta if b >= 0 and (5 * delta <= len(ch) or delta + 8 < full) else full
     return n, stored, cuts, uniq, base
 
 
@@ -101,7 +105,8 @@ def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
     O.build()
     cores = os.cpu_count() or 1
     seg = 4 << 20
-    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 64)
+    # every host core gets work: two 4 MiB segments per core (bounded at 2 GiB), ~3 s of one-core work each
+    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 512)
     nseg = max(1, min(nseg, host.size // seg))
     segs = [(host[i * seg:(i + 1) * seg], {}) for i in range(nseg)]
     workers = min(cores, nseg)
@@ -235,11 +240,14 @@ def main():
 
     # per-kernel durations of the timed steps (HIP events on the launch stream, inside the C-ABI)
     kern = {}
+    tokens = {}          # tokens written (match kernels) / read (encode kernels) per launch, counted on the device
     for s, name in STAGE_NAMES.items():
-        ms, n = C.c_double(), C.c_uint64()
+        ms, n, tk = C.c_double(), C.c_uint64(), C.c_uint64()
         lib.hmse_profile_read(s, C.byref(ms), C.byref(n), 1)
+        lib.hmse_profile_counter(s, C.byref(tk), 1)
         if n.value:
             kern[name] = {"avg_ms": ms.value / n.value, "launches": int(n.value)}
+            tokens[name] = tk.value / n.value
     st = ingest.shard_stats(res)
     # algorithmic bytes per launch: L2/L3 read every input byte once; L4a reads the unique
     # bytes; L1 reads unique + dictionary bytes and writes the streams
@@ -257,22 +265,24 @@ def main():
         dl = torch.clamp(ul[res.base.clamp(min=0)], max=32768) if res.base is not None else torch.zeros_like(ul)
         # match jobs: one per chunk — its own window, or chunk + dictionary for a chunk with a base (that job emits both the
         # FULL and the DELTA token list); encode jobs: one per record
-        enc_L = torch.cat([ul, ul[hb]])
-        cf_l1 = st["unique_bytes"] / max(1, st["stored_bytes"])
 
         def by_class(T, Ltok, off):
             cls = torch.where(T <= 9216, 0, torch.where(T <= 12288, 4, torch.where(T <= 16000, 5, torch.where(T <= 21504, 1, torch.where(T <= 32768, 2, 3)))))
             for c, slot in DEFLATE_CLASS_SLOT.items():
                 m = cls == c
-                # match kernel: window read + token list(s) written (4 B per token, ~ one token per 3.5 positions)
-                alg[STAGE_NAMES[slot + off]] = int(T[m].sum().item() + 1.15 * Ltok[m].sum().item())
+                # match kernel: window read + token list written (4 B per token, COUNTED by the kernel: hmse_profile_counter)
+                alg[STAGE_NAMES[slot + off]] = int(T[m].sum().item() + 4 * tokens.get(STAGE_NAMES[slot + off], 0))
 
         by_class(ul[~hb], ul[~hb], 0)                # plain jobs
-        by_class((ul + dl)[hb], 2 * ul[hb], 10)      # dictionary jobs: two token lists
-        for slot, lo, hi in ((14, 0, 12288), (15, 12288, 32768)):
-            m = (enc_L > lo) & (enc_L <= hi)
-            # encode kernel: token list read, stream written
-            alg[STAGE_NAMES[slot]] = int((1.15 + 1.0 / cf_l1) * enc_L[m].sum().item())
+        by_class((ul + dl)[hb], ul[hb], 10)          # dictionary jobs (one token list: the DELTA record's)
+        for slot in (14, 15):
+            # encode kernel: token list read (counted), stream written (share of the stored bytes by token share)
+            alg[STAGE_NAMES[slot]] = int(4 * tokens.get(STAGE_NAMES[slot], 0))
+        tot_tok = sum(tokens.get(STAGE_NAMES[sl], 0) for sl in (14, 15)) or 1
+        for slot in (14, 15):
+            alg[STAGE_NAMES[slot]] += int(st["stored_bytes"] * tokens.get(STAGE_NAMES[slot], 0) / tot_tok)
+        for slot in list(range(24, 32)):             # second pass: token traffic only (its windows are not tracked per class here)
+            alg[STAGE_NAMES[slot]] = int(4 * tokens.get(STAGE_NAMES[slot], 0))
     stage_roof = {}
     for name, k in kern.items():
         if name not in alg:

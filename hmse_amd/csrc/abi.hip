@@ -148,7 +148,26 @@ void hmse_prof_end(int stage, hipStream_t s) {
   (void)hipEventRecord(p.e1[p.n], s);
   p.n++;
 }
-extern "C" void hmse_profile_enable(int on) { g_hmse_prof = on; }
+// device-side work counters of the diagnostics (tokens written / read by the DEFLATE kernels, per profile slot): allocated
+// by the first hmse_profile_enable(1) — the ONE allocation this library makes, and only on the diagnostics path
+unsigned long long* g_hmse_prof_ctr = nullptr;
+extern "C" void hmse_profile_enable(int on) {
+  if (on && !g_hmse_prof_ctr) {
+    if (hipMalloc((void**)&g_hmse_prof_ctr, 32 * sizeof(unsigned long long)) != hipSuccess) g_hmse_prof_ctr = nullptr;
+    else (void)hipMemset(g_hmse_prof_ctr, 0, 32 * sizeof(unsigned long long));
+  }
+  g_hmse_prof = on;
+}
+extern "C" int hmse_profile_counter(int slot, uint64_t* value, int reset) {
+  if (slot < 0 || slot > 31 || !value) return HMSE_EINVAL;
+  *value = 0;
+  if (!g_hmse_prof_ctr) return HMSE_OK;
+  unsigned long long v = 0;
+  if (hipMemcpy(&v, g_hmse_prof_ctr + slot, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return HMSE_EHIP;
+  *value = v;
+  if (reset) { v = 0; if (hipMemcpy(g_hmse_prof_ctr + slot, &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) return HMSE_EHIP; }
+  return HMSE_OK;
+}
 extern "C" int hmse_profile_read(int stage, double* total_ms, uint64_t* launches, int reset) {
   if (stage < 0 || stage > 31) return HMSE_EINVAL;
   ProfStage& p = g_ps[stage];

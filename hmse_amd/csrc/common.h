@@ -92,6 +92,7 @@ int hmse_fill_async(void* p, uint32_t byte_value, size_t bytes, hipStream_t stre
 
 // diagnostics: event pair around a stage's dominant kernel (see hmse_profile_enable)
 extern int g_hmse_prof;
+extern unsigned long long* g_hmse_prof_ctr;   // DEVICE u64[32] work counters per profile slot (nullptr until profiling was enabled once)
 void hmse_prof_begin(int stage, hipStream_t s);
 void hmse_prof_end(int stage, hipStream_t s);
 #define PROF_BEGIN(stage, s) do { if (g_hmse_prof) hmse_prof_begin(stage, s); } while (0)

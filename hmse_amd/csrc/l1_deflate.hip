@@ -21,6 +21,8 @@
 // length; encode kernel: one 256-thread workgroup per job, six per CU.  Persistent workgroups pull jobs from
 // per-class lists.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace dfl {
 
@@ -85,6 +87,14 @@ __device__ __forceinline__ uint32_t len_extra_bits(uint32_t code) {  // code 257
 __device__ __forceinline__ uint32_t dist_extra_bits(uint32_t code) { return code < 4 ? 0 : (code >> 1) - 1; }
 __device__ __forceinline__ uint32_t fixed_len(uint32_t s) { return s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8; }
 
+// A value that IS the same in every lane, told to the compiler (SGPRs): control flow that depends only on such values becomes
+// scalar branches — no EXEC masking, so a cross-lane read inside it (readfirstlane, bpermute from lane 0) always finds its source
+// lane active.  (Round 3: the dictionary jobs' work queue was wave-uniform in fact but divergent in the compiler's analysis — the
+// chunk length it compared against came from a vector load — and the structurised loop it produced never finished on the first
+// shard with more class-S dictionary jobs than resident workgroups; profiles/r3/r3_deflate_dict_queue_hang_isa.txt.)
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+
 // order LDS traffic between the lanes of one wavefront (no instruction is emitted for the barrier itself)
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -113,6 +123,7 @@ struct Small {
   uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
   uint32_t job, qhead;
   uint32_t pexit[NT / 64], pexit2[NT / 64], pconv[NT / 64];
+  uint8_t wtab[NT];   // dictionary jobs: per wavefront, lane that holds the r-th pending work rank of the wave's window
 };
 
 constexpr int align16(int v) { return (v + 15) & ~15; }
@@ -343,7 +354,7 @@ __device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint3
 
 #ifdef HMSE_DFL_STAMPS
 // diagnostic build only: per-phase shader-clock totals of thread 0, summed over jobs and workgroups
-__device__ unsigned long long g_dfl_stamps[3][16];
+__device__ unsigned long long g_dfl_stamps[6][16];   // [size group + 3 * dictionary jobs][phase]
 __device__ unsigned long long g_enc_stamps[8];   // encode kernel: clocks of thread 0 per phase (0 load, 1 trees, 2 rle+cl+decide, 3 codes, 4 emit, 5 copy-out), [7] records
 #define STAMP(i) do { if (t == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
 #else
@@ -373,6 +384,7 @@ struct Args {
   uint8_t* scratch; size_t scratch_stride;   // !LDSM only
   uint8_t* scratch2; size_t scratch2_stride; // match lengths/distances of the classes that keep them out of LDS
   const uint32_t* jobs; const uint32_t* n_jobs; uint32_t* counter;  // this class's job list
+  unsigned long long* prof_ctr; uint32_t prof_slot;                  // diagnostics: tokens written (match) / read (encode) by this launch
 };
 
 
@@ -433,15 +445,10 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
     uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
     uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
-    // A dictionary job (variant 1) also yields the chunk's FULL encoding: candidates are walked nearest first and every
-    // chunk position precedes every dictionary position, so the state of the walk when it reaches the first dictionary
-    // candidate IS the result of the FULL walk (same candidates, same depth cut, same filters).  That snapshot goes to a
-    // second pair of arrays (second half of the per-workgroup global scratch) and is parsed and tokenised in a second
-    // pass below: one sort and one walk serve both records, and no separate FULL job runs for a chunk that has a base.
-    uint16_t* const mdistF = (uint16_t*)((uint8_t*)mdist_g + 3 * 32768);
-    uint8_t* const mlenF = (uint8_t*)(mdistF + LCAP);
+    // A dictionary job yields the chunk's DELTA record only (round 3, rule 7 of the oracle): the FULL record of a chunk with a
+    // base is produced by a plain job in a second pass, and only when the delta turns out larger than a fifth of the chunk.
     if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.rec_off[k] + (variant + 1ull) * rec_size(L) > a.rec_cap) {
-      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (variant) a.len_full[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small (a dictionary job carries the FULL record too)
+      if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
       continue;
     }
     const uint8_t* csrc = a.data + cstart;
@@ -464,7 +471,6 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     if (t == 0) sm.qhead = 0;
     // (16 bytes per store: both arrays start on a 16-byte boundary and hold LCAP = a multiple of 16 bytes)
     for (uint32_t i = t * 16; i < L; i += NT * 16) *(uint4*)(mlen + i) = make_uint4(0, 0, 0, 0);
-    if (variant) for (uint32_t i = t * 16; i < L; i += NT * 16) *(uint4*)(mlenF + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     STAMP(0);
@@ -592,17 +598,126 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     // one u16 read of the bucket array and one 4-byte probe at offset best-3 (a longer match must agree
     // there); the first 16 bytes of the p side are compared from registers.  Candidate order per
     // position is unchanged (nearest first), so results equal the oracle's serial walk.
+    //
+    // Dictionary jobs (rule 2c of the oracle): a position with a diagonal hint (>= 16 bytes of an anchor's run left) TAKES it — no
+    // walk.  Those are ~85 % of a near-duplicate's positions; a position-parallel pre-pass writes their results with coalesced stores,
+    // and the state machine below only ever sees the others: every wavefront scans the sorted ranks 64 at a time, keeps the
+    // ranks that need a walk (chunk positions without a hint) as a 64-bit window mask, and hands them to its idle
+    // lanes in order — no lane ever pulls a dictionary rank or a hinted position.
+    // diagonal hint of chunk position p: best (known length, candidate) over this block's anchor and the previous one's
+    auto hint_of = [&](uint32_t p, uint32_t maxlen, uint32_t& bq) -> uint32_t {
+      const uint32_t a0 = (p - Dl) >> 6;
+      uint32_t bm = 0; bq = 0;
+#pragma unroll
+      for (uint32_t back = 0; back < 2; back++) {
+        if (a0 < back) continue;
+        const uint32_t w = anch[a0 - back];
+        const uint32_t d = w & 0xFFFFu, run = w >> 16, pa = Dl + ((a0 - back) << 6);
+        if (w == 0 || p < pa || d > p || p - d >= Dl) continue;      // (p < pa cannot happen: this block's anchor IS p's block start)
+        uint32_t m = 0;
+        if (run >= 512u) m = maxlen;                                   // no mismatch within 512 bytes: >= 385 from here
+        else if (pa + run > p) m = (pa + run - p) < maxlen ? (pa + run - p) : maxlen;
+        if (m > bm) { bm = m; bq = p - d; }
+      }
+      return bm;
+    };
+    if constexpr (DICT) {
+      for (uint32_t x = t; x < L; x += NT) {
+        const uint32_t p = Dl + x;
+        if (p + 4 > T) continue;
+        const uint32_t maxlen = (T - p) < MAXM ? (T - p) : MAXM;
+        uint32_t bq;
+        const uint32_t bm = hint_of(p, maxlen, bq);
+        if (bm >= 16u) { mlen[x] = (uint8_t)(bm - 3); mdist[x] = (uint16_t)(p - bq); }
+      }
+      // (no barrier needed: the state machine never touches a hinted position's slots, and the parse starts behind a barrier)
+    }
+    STAMP(6);
     {
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
-      uint32_t ph = 0;   // dictionary jobs: diagonal hint of the current position, q' | known length << 16 (0 = none)
+      // dictionary jobs: this wavefront's window of pending work ranks (wave-uniform)
+      uint64_t wq_mask = 0; uint32_t wq_base = 0; bool wq_done = false;
+      const uint32_t nh_s = uni32(nh);
+      uint8_t* const wtab = sm.wtab + (wave << 6);
+      // state of a freshly pulled position (rank ii holds chunk position pp)
+      auto begin_walk = [&](uint32_t ii, uint32_t pp) {
+        i = ii; p = pp;
+        qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
+        kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
+        ld64a(W, p, pw0, pw1);
+        const uint32_t h = hash4(pw0);
+        const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
+        maxlen = (T - p) < MAXM ? (T - p) : MAXM;
+        kmax = i - lo;
+        if (kmax > a.depth) kmax = a.depth;
+        best = MINM - 1; bd = 0; probe = pw0; kk = 1;
+#ifdef HMSE_DFL_STAMPS
+        if (DICT && t == 0) stamp_acc[7]++;  // lane 0's walked positions
+#endif
+        if (kmax != 0) st = PROBE;  // (else: first of its bucket, no match — the lane pulls again)
+      };
+      // every wavefront leaves this loop: by running out of work, or — never observed on a correct build — by using up a trip
+      // budget no legal walk can reach (status bit 4: the job's record is then garbage and the call reports it)
+      const uint32_t trip_budget = (nh + 64u) * (a.depth + 16u);
+      uint32_t trips = 0;
       for (;;) {
 #ifdef HMSE_DFL_STAMPS
         if (t == 0) stamp_acc[13]++;  // trips of wavefront 0 through the state machine
 #endif
-        const uint64_t need = __ballot(st == FETCH);
-        if (need) {  // wave-aggregated pull of the next sorted ranks
+        if (++trips > uni32(trip_budget)) {
+#ifdef HMSE_DIAG
+          const uint64_t sf = __ballot(st == FETCH), sp = __ballot(st == PROBE), se = __ballot(st == EXTEND);
+          if (lane == 0) printf("[dfl] trip budget: job %u k %llu L %u Dl %u nh %u wave %u qhead %u wq_base %u wq_mask %llx wq_done %d FETCH %llx PROBE %llx EXTEND %llx p %u kk %u kmax %u best %u ml %u maxlen %u q %u\n",
+                                ji, (unsigned long long)k, L, Dl, nh, wave, sm.qhead, wq_base, (unsigned long long)wq_mask, (int)wq_done, (unsigned long long)sf, (unsigned long long)sp, (unsigned long long)se, p, kk, kmax, best, ml, maxlen, q);
+#endif
+          if (lane == 0) atomicOr(a.status, 16u);
+          break;
+        }
+        uint64_t need = uni64(__ballot(st == FETCH));
+        if constexpr (DICT) {
+          // serve the idle lanes from the wavefront's window; scan the next 64 sorted ranks when it is empty.  Everything that
+          // steers this loop (need, wq_mask, wq_base, wq_done, nh_s) is wave-uniform AND scalar (uni32 / uni64)
+          for (int it = 0; need != 0 && it < 6; it++) {
+            if (wq_mask == 0) {
+              if (wq_done) break;
+              uint32_t b = 0;
+              if (lane == 0) b = atomicAdd(&sm.qhead, 64u);
+              b = uni32(b);
+              if (b >= nh_s) { wq_done = true; break; }
+              wq_base = b;
+              const uint32_t ii = b + lane;
+              bool work = false;
+              if (ii < nh_s) {
+                const uint32_t pp = S[ii];
+                if (pp >= Dl) {
+                  const uint32_t mx = (T - pp) < MAXM ? (T - pp) : MAXM;
+                  uint32_t bq;
+                  const uint32_t bm = hint_of(pp, mx, bq);
+                  work = bm < 16u;
+                }
+              }
+              wq_mask = uni64(__ballot(work));
+              if (wq_mask == 0) continue;
+            }
+            const uint32_t navail = (uint32_t)__builtin_popcountll(wq_mask), nneed = (uint32_t)__builtin_popcountll(need);
+            const uint32_t take_n = navail < nneed ? navail : nneed;
+            const bool has = (wq_mask >> lane) & 1ull;
+            const uint32_t rm = mbcnt64(wq_mask);
+            if (has && rm < take_n) wtab[rm] = (uint8_t)lane;
+            wave_sync();
+            const bool isneed = (need >> lane) & 1ull;
+            const uint32_t rn = mbcnt64(need);
+            uint32_t got = 0xFFFFFFFFu;
+            if (isneed && rn < take_n) got = wq_base + (uint32_t)wtab[rn];
+            wave_sync();
+            wq_mask &= ~uni64(__ballot(has && rm < take_n));
+            need &= ~uni64(__ballot(isneed && rn < take_n));
+            if (got != 0xFFFFFFFFu) begin_walk(got, (uint32_t)S[got]);
+          }
+          if (wq_done && wq_mask == 0 && st == FETCH) st = DONE;
+        } else if (need) {  // wave-aggregated pull of the next sorted ranks
           const uint32_t leader = (uint32_t)__builtin_ctzll(need);
           uint32_t base = 0;
           if (lane == leader) base = atomicAdd(&sm.qhead, (uint32_t)__builtin_popcountll(need));
@@ -610,84 +725,25 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (st == FETCH) {
             const uint32_t ii = base + mbcnt64(need);
             if (ii >= nh) st = DONE;
-            else {
-              const uint32_t pp = S[ii];
-              if (pp >= Dl) {  // dictionary positions are candidates only: the lane pulls again next round
-                i = ii; p = pp;
-                qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
-                kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
-                ld64a(W, p, pw0, pw1);
-                const uint32_t h = hash4(pw0);
-                const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
-                maxlen = (T - p) < MAXM ? (T - p) : MAXM;
-                kmax = i - lo;
-                if (kmax > a.depth) kmax = a.depth;
-                best = MINM - 1; bd = 0; probe = pw0; kk = 1;
-                if constexpr (DICT) {
-                  // diagonal hint: a dictionary candidate q' = p - d of this position whose common prefix with p is known
-                  // exactly from an anchor's run (this block's anchor or the previous one's), usable iff q' is one of the
-                  // candidates the walk will reach
-                  ph = 0;
-                  if (kmax != 0) {
-                    const uint32_t a0 = (p - Dl) >> 6;
-                    uint32_t bm = 0, bq = 0;
-#pragma unroll
-                    for (uint32_t back = 0; back < 2; back++) {
-                      if (a0 < back) continue;
-                      const uint32_t w = anch[a0 - back];
-                      const uint32_t d = w & 0xFFFFu, run = w >> 16, pa = Dl + ((a0 - back) << 6);
-                      if (w == 0 || p < pa || d > p || p - d >= Dl) continue;      // (p < pa: this block's anchor IS p's block start)
-                      uint32_t m = 0;
-                      if (run >= 512u) m = maxlen;                                   // no mismatch within 512 bytes: >= 385 from here
-                      else if (pa + run > p) m = (pa + run - p) < maxlen ? (pa + run - p) : maxlen;
-                      if (m > bm) { bm = m; bq = p - d; }
-                    }
-                    // a hint of the full length min(258, T - p) is TAKEN by definition when the walk leaves the chunk (rule 2b of
-                    // the oracle): bit 31.  A shorter one only spares the byte compare of a candidate the walk reaches anyway.
-                    if (bm >= 16u && bm == maxlen) ph = bq | (bm << 16) | 0x80000000u;
-                    else if (bm >= 16u && (uint32_t)S[i - kmax] <= bq) ph = bq | (bm << 16);
-#ifdef HMSE_DFL_STAMPS
-                    if (t == 0) { stamp_acc[6]++; if (bm >= 16u) stamp_acc[7]++; if (ph) stamp_acc[8]++; }  // lane 0's positions: fetched / hinted / usable
-#endif
-                  }
-                }
-                if (kmax != 0) st = PROBE;  // first of its bucket: no match, pull again
-              }
-            }
+            else begin_walk(ii, (uint32_t)S[ii]);
           }
         }
-        if (__ballot(st != DONE) == 0) break;
+        if (uni64(__ballot(st != DONE)) == 0) break;
         bool fin = false;  // candidate kk finished with length ml
         if (st == PROBE) {
           q = qn;
           uint32_t kb = kn;
           if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }  // prefetch the next candidate
-          // first dictionary candidate of this position: what the walk holds now is the FULL result (bit 31 of bd = done)
-          if (variant && q < Dl && !(bd >> 31)) {
-            if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
-            bd |= 0x80000000u;
-            // with a hint, candidate q' (farther on in this walk) is known to reach ph >> 16 bytes: a nearer dictionary candidate
-            // only matters if it reaches as many (it then wins the tie), so the filters may already work with that length
-            if (DICT && (ph >> 31)) q = ph & 0xFFFFu;   // full-length hint: the walk's dictionary part IS this one candidate
-            else if (DICT && ph && ((ph >> 16) & 0x7FFFu) - 1u > best) { best = ((ph >> 16) & 0x7FFFu) - 1u; probe = ld32a(W, p + best - 3); }
-          }
           // a candidate the byte-4 filter rejects (37 % of them on text) is consumed on the spot and the next one takes
           // its place in this trip: the filter needs nothing but the two prefetched values
           // (classes with the filter array only: where byte 4 is a dependent window read the second test costs more than it saves)
-          if (!NOK && best >= 4 && kb != (pw1 & 0xFFu) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX) && !(DICT && (ph >> 31) && q == (ph & 0xFFFFu))) {
+          if (!NOK && best >= 4 && kb != (pw1 & 0xFFu) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX) ) {
             kk++;
             q = qn; kb = kn;
             if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }
-            if (variant && q < Dl && !(bd >> 31)) {
-              if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
-              bd |= 0x80000000u;
-              if (DICT && (ph >> 31)) q = ph & 0xFFFFu;
-              else if (DICT && ph && ((ph >> 16) & 0x7FFFu) - 1u > best) { best = ((ph >> 16) & 0x7FFFu) - 1u; probe = ld32a(W, p + best - 3); }
-            }
           }
           fin = true; ml = 0;
-          if (DICT && ph && q == (ph & 0xFFFFu) && ((bd >> 31) || !(ph >> 31))) ml = (ph >> 16) & 0x7FFFu;  // the hinted candidate: its length is known, no byte is read
-          else if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;        // farther ones are farther still
+          if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
           else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
           else {
             // random-address window reads only for candidates that can still win
@@ -729,20 +785,13 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (ml > maxlen) ml = maxlen;
           bool pos_done = false;
           if (ml > best) {
-            best = ml; bd = (bd & 0x80000000u) | (p - q);
+            best = ml; bd = p - q;
             if (ml == maxlen) pos_done = true; else probe = ld32a(W, p + best - 3);
           }
           if (++kk > kmax) pos_done = true;
           st = PROBE;
           if (pos_done) {
-            if (DICT && (ph >> 31) && !(bd >> 31) && best < maxlen) {
-              // depth used up inside the chunk while a full-length hint is pending: FULL = what the walk holds, DELTA = the hint
-              if (best >= MINM) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }
-              mlen[p - Dl] = (uint8_t)(maxlen - 3); mdist[p - Dl] = (uint16_t)(p - (ph & 0xFFFFu));
-            } else if (best >= MINM) {
-              mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd;
-              if (variant && !(bd >> 31)) { mlenF[p - Dl] = (uint8_t)(best - 3); mdistF[p - Dl] = (uint16_t)bd; }  // never reached the dictionary
-            }
+            if (best >= MINM) { mlen[p - Dl] = (uint8_t)(best - 3); mdist[p - Dl] = (uint16_t)bd; }
             st = FETCH;
           }
         }
@@ -751,16 +800,13 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     __syncthreads();
     for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;   // (held the diagonal anchors of a dictionary job until here)
     STAMP(3);
-    // pass 0: this job's own record (DELTA for a dictionary job); pass 1 (dictionary jobs only): the FULL record
-    for (uint32_t pass = 0; pass < (variant ? 2u : 1u); pass++) {
-    const uint8_t* mlen_c = pass ? mlenF : mlen;
-    // Match lengths that live in HBM (the FULL snapshot of a dictionary job; every length array of the classes that keep
-    // them out of LDS) are staged into a free LDS region first: the parse reads each of them three times.
+    const uint8_t* mlen_c = mlen;
+    // Match lengths that live in HBM (the classes that keep them out of LDS) are staged into a free LDS region first: the
+    // parse reads each of them three times.
     {
       uint8_t* stage = nullptr;
       if constexpr (!LDSM) stage = smem + LY::A_OFF;                                   // unused by this kernel in class B
-      else if constexpr (!MLG) { if (pass) stage = smem + LY::ML_OFF; }                // the DELTA lengths are dead by now
-      else {
+      else if constexpr (MLG) {
         const uint32_t joff = (2u * (L + 1u) + 15u) & ~15u;                            // behind the next-pointers
         if (joff + L + 16u <= (uint32_t)LY::A_SZ) stage = smem + LY::A_OFF + joff;
       }
@@ -771,14 +817,8 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         __syncthreads();
       }
     }
-    const uint16_t* const mdist_c = pass ? mdistF : mdist;
-    uint8_t* const rec_c = pass ? a.recs + a.rec_off[k] : rec;
-    if (pass) {
-      __syncthreads();  // histograms of pass 0 have been copied out
-      for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
-      if (t < 32) sm.df[t] = 0;
-      __syncthreads();
-    }
+    const uint16_t* const mdist_c = mdist;
+    uint8_t* const rec_c = rec;
     // ---- phase 6: parse by pointer doubling -------------------------------------------------------
     auto take = [&](uint32_t x) -> bool {
       const uint32_t ml = mlen_c[x];
@@ -933,21 +973,20 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           idx++;
         }
       }
-      if (t == 0) { atomicAdd(&sm.lf[256], 1u); *(uint32_t*)(rec_c + rec_ntok_off()) = ntok; }
+      if (t == 0) { atomicAdd(&sm.lf[256], 1u); *(uint32_t*)(rec_c + rec_ntok_off()) = ntok; if (a.prof_ctr) atomicAdd(&a.prof_ctr[a.prof_slot], (unsigned long long)ntok); }
       __syncthreads();
       STAMP(5);
       uint32_t* const r_hist = (uint32_t*)rec_c;
       for (uint32_t i = t; i < 288; i += NT) r_hist[i] = sm.lf[i];
       if (t < 32) r_hist[288 + t] = sm.df[t];
     }
-    }  // pass
     STAMP(9);
 #ifdef HMSE_DFL_STAMPS
     if (t == 0) { stamp_acc[14] += L; stamp_acc[15]++; }
 #endif
   }
 #ifdef HMSE_DFL_STAMPS
-  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2][i], stamp_acc[i]);
+  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
 #endif
 }
 
@@ -1001,6 +1040,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   const uint32_t* const r_hist = (const uint32_t*)rec;
   const uint32_t ntok = *(const uint32_t*)(rec + rec_ntok_off());
   const uint32_t* const tok = (const uint32_t*)(rec + rec_tok_off());
+  if (a.prof_ctr && t == 0) atomicAdd(&a.prof_ctr[a.prof_slot], (unsigned long long)ntok);
   uint8_t* const slot = rec + rec_slot_off(L);
   const uint8_t* const lit = a.data + cstart;
   for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = r_hist[i];
@@ -1196,34 +1236,45 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
 constexpr int NT_M = 1024, TCAP_SG3 = 32768;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_LIST = 15;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); encode-kernel lists by
-                                // chunk length: 6 and 7; dictionary jobs per class: lists 9..14 (dict_list)
+constexpr int N_LIST = 23;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); encode-kernel lists by
+                                // chunk length: 6 and 7; dictionary jobs per class: lists 9..14 (dict_list); second pass (FULL records of
+                                // chunks whose delta is no quick accept, rule 7): plain jobs 15..20 (redo_list), encode 21 and 22
+constexpr int N_CTR = 64;       // u32 counters: [c] = jobs in list c, [32 + c] = list c's cursor
 __host__ __device__ constexpr uint32_t dict_list(uint32_t c) { return c == 0 ? 9u : c == 4 ? 10u : c == 5 ? 11u : c == 8 ? 12u : c == 2 ? 13u : 14u; }
+__host__ __device__ constexpr uint32_t redo_list(uint32_t c) { return c == 0 ? 15u : c == 4 ? 16u : c == 5 ? 17u : c == 8 ? 18u : c == 2 ? 19u : 20u; }
+__host__ __device__ __forceinline__ uint32_t size_class(uint64_t T) {
+  return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_SG2 ? 8u : T <= (uint64_t)TCAP_SG3 ? 2u : 3u;
+}
+// rule 7 of the oracle: a delta of at most a fifth of the chunk (README.md:1328, 2175) is the record without a look at FULL
+__host__ __device__ __forceinline__ bool delta_gate(uint32_t n2, uint64_t len, uint32_t pct) { return n2 != 0xFFFFFFFFu && n2 != 0u && !(pct && (uint64_t)n2 * 100 > (uint64_t)pct * len); }
+__host__ __device__ __forceinline__ bool delta_quick(uint32_t n2, uint64_t len, uint32_t pct) { return delta_gate(n2, len, pct) && (uint64_t)n2 * 5 <= len; }
 static_assert(2 * Layout<NT_S, TCAP_S, TCAP_S, true>::TOTAL <= 160 * 1024, "class S must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 1024, "class S2 must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>::TOTAL <= 160 * 1024, "class SG2 must fit twice per CU");
 
-// job = (k << 1) | variant, appended to its size class's list
+// wave-aggregated append of `job` to list `cl` (one atomic per list per wavefront instead of one per job); all lanes call it
+__device__ __forceinline__ void list_append(bool on, uint32_t cl, uint32_t job, uint32_t* lists, uint64_t list_stride, uint32_t* counts) {
+#pragma unroll 1
+  for (uint32_t c = 0; c < (uint32_t)N_LIST; c++) {
+    const uint64_t m = __ballot(on && cl == c);
+    if (m == 0) continue;
+    uint32_t base0 = 0;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    if (lane_id() == leader) base0 = atomicAdd(&counts[c], (uint32_t)__builtin_popcountll(m));
+    base0 = (uint32_t)__builtin_amdgcn_readlane((int)base0, (int)leader);
+    if (on && cl == c) lists[(size_t)c * list_stride + base0 + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = job;
+  }
+}
+
+// job = (k << 1) | variant, appended to its size class's list.  A chunk with a base gets a dictionary job (its DELTA record)
+// and nothing else in this pass; a chunk without one a plain job (its FULL record).
 __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel, uint32_t base_is_chunk,
                                                         uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts,
                                                         const uint64_t* __restrict__ n_dev) {
   if (n_dev) n_sel = *n_dev;   // captured chain: the count lives in HBM, the grid is sized for the worst case
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // wave-aggregated append (one atomic per class per wavefront instead of one per job)
-  auto append = [&](bool on, uint32_t cl, uint32_t job) {
-#pragma unroll
-    for (uint32_t c = 0; c < (uint32_t)N_LIST; c++) {
-      const uint64_t m = __ballot(on && cl == c);
-      if (m == 0) continue;
-      uint32_t base0 = 0;
-      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-      if (lane_id() == leader) base0 = atomicAdd(&counts[c], (uint32_t)__builtin_popcountll(m));
-      base0 = (uint32_t)__builtin_amdgcn_readlane((int)base0, (int)leader);
-      if (on && cl == c) lists[(size_t)c * list_stride + base0 + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = job;
-    }
-  };
   const bool in = k < n_sel;
   uint64_t L = 0; bool hasb = false; uint64_t Dl = 0;
   if (in) {
@@ -1236,15 +1287,27 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
       hasb = true;
     }
   }
-  auto cls = [&](uint64_t T) -> uint32_t {
-    return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_SG2 ? 8u
-           : T <= (uint64_t)TCAP_SG3 ? 2u : 3u;
-  };
   const bool enc_ok = in && L <= 32768;
-  append(in && !hasb, cls(L), (uint32_t)(k << 1));  // a chunk with a base gets its FULL record from the dictionary job
-  append(in && hasb, dict_list(cls(L + Dl)), (uint32_t)((k << 1) | 1u));
-  append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1));
-  append(enc_ok && hasb, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | 1u));
+  list_append(in && !hasb, size_class(L), (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append(in && hasb, dict_list(size_class(L + Dl)), (uint32_t)((k << 1) | 1u), lists, list_stride, counts);
+  list_append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | (hasb ? 1u : 0u)), lists, list_stride, counts);
+}
+
+// second pass (rule 7): chunks with a base whose delta is no quick accept need their FULL record after all
+__global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
+                                                    const int64_t* __restrict__ base, uint64_t n_sel, const uint32_t* __restrict__ len_delta,
+                                                    uint32_t pct, uint32_t* __restrict__ lists, uint64_t list_stride,
+                                                    uint32_t* __restrict__ counts, const uint64_t* __restrict__ n_dev) {
+  if (n_dev) n_sel = *n_dev;
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool redo = false; uint64_t L = 0;
+  if (k < n_sel && base && base[k] >= 0) {
+    const uint64_t c = chunk_ids ? chunk_ids[k] : k;
+    L = cuts[c + 1] - cuts[c];
+    redo = !delta_quick(len_delta[k], L, pct);
+  }
+  list_append(redo, redo_list(size_class(L)), (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append(redo && L <= 32768, L <= 12288 ? 21u : 22u, (uint32_t)(k << 1), lists, list_stride, counts);
 }
 
 // record sizes: FULL (+ DELTA when a base exists)
@@ -1260,7 +1323,7 @@ __global__ __launch_bounds__(256) void rec_size_kernel(const uint64_t* __restric
   sizes[k] = (base && base[k] >= 0) ? 2 * s : s;
 }
 
-// kind decision (README.md:1328, 2175 as resolved by SURVEY.md D7) and final lengths
+// kind decision (rule 7 of the oracle; README.md:1328, 2175) and final lengths
 __global__ __launch_bounds__(256) void decide_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                       const int64_t* __restrict__ base, uint64_t n_sel,
                                                       const uint32_t* __restrict__ len_full, const uint32_t* __restrict__ len_delta,
@@ -1269,16 +1332,22 @@ __global__ __launch_bounds__(256) void decide_kernel(const uint64_t* __restrict_
   if (n_dev) n_sel = *n_dev;
   const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_sel) return;
-  const uint32_t n1 = len_full[k];
-  uint32_t n = n1; uint8_t kd = HMSE_KIND_FULL;
-  if (n1 == 0xFFFFFFFFu || n1 == 0u) { atomicOr(status, n1 ? 4u : 8u); n = 0; }  // not encodable / never encoded
-  else if (base && base[k] >= 0) {
+  uint32_t n = 0; uint8_t kd = HMSE_KIND_FULL;
+  bool done = false;
+  if (base && base[k] >= 0) {
     const uint32_t n2 = len_delta[k];
     const uint64_t c = chunk_ids ? chunk_ids[k] : k;
     const uint64_t len = cuts[c + 1] - cuts[c];
-    bool ok = n2 != 0xFFFFFFFFu && (uint64_t)n2 + 8 < n1;
-    if (pct && (uint64_t)n2 * 100 > (uint64_t)pct * len) ok = false;
-    if (ok) { n = n2; kd = HMSE_KIND_DELTA; }
+    if (delta_quick(n2, len, pct)) { n = n2; kd = HMSE_KIND_DELTA; done = true; }        // FULL was never computed
+    else {
+      const uint32_t n1 = len_full[k];
+      if (n1 != 0xFFFFFFFFu && n1 != 0u && delta_gate(n2, len, pct) && (uint64_t)n2 + 8 < n1) { n = n2; kd = HMSE_KIND_DELTA; done = true; }
+    }
+  }
+  if (!done) {
+    const uint32_t n1 = len_full[k];
+    if (n1 == 0xFFFFFFFFu || n1 == 0u) { atomicOr(status, n1 ? 4u : 8u); n = 0; }  // not encodable / never encoded
+    else n = n1;
   }
   final_len[k] = n;
   if (kind) kind[k] = kd;
@@ -1375,7 +1444,7 @@ static int exclusive_scan_u64(const uint64_t* in, uint64_t n, uint64_t* out, uin
 constexpr int N_WG_B = 256;  // persistent workgroups of the big class (one per CU, global scratch each)
 
 struct Ws {
-  uint32_t* counters;  // [0..8] job counts per list, [16..24] job cursors
+  uint32_t* counters;  // [c] job count of list c, [32 + c] its cursor
   uint64_t* rec_off; uint64_t* final_len; uint64_t* bsum; uint64_t* rec_total;
   uint32_t* len_full; uint32_t* len_delta; uint32_t* lists; uint64_t list_stride;
   uint8_t* scratch; uint8_t* scratch2; uint8_t* recs; size_t fixed_bytes;
@@ -1383,7 +1452,7 @@ struct Ws {
 static Ws carve(void* ws, uint64_t n_sel) {
   WsCarver w(ws, ~(size_t)0);
   Ws r;
-  r.counters = w.take<uint32_t>(32);
+  r.counters = w.take<uint32_t>(N_CTR);
   r.rec_total = w.take<uint64_t>(1);
   r.rec_off = w.take<uint64_t>(n_sel + 1);
   r.final_len = w.take<uint64_t>(n_sel + 1);
@@ -1420,9 +1489,9 @@ extern "C" int hmse_debug_encode_stamps(unsigned long long* out8, int reset) {
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_enc_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
   return HMSE_OK;
 }
-extern "C" int hmse_debug_deflate_stamps(unsigned long long* out48, int reset) {
-  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(dfl::g_dfl_stamps), sizeof(dfl::g_dfl_stamps)) != hipSuccess) return HMSE_EHIP;
-  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
+extern "C" int hmse_debug_deflate_stamps(unsigned long long* out96, int reset) {
+  if (hipMemcpyFromSymbol(out96, HIP_SYMBOL(dfl::g_dfl_stamps), sizeof(dfl::g_dfl_stamps)) != hipSuccess) return HMSE_EHIP;
+  if (reset) { unsigned long long z[96] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
   return HMSE_OK;
 }
 #endif
@@ -1476,7 +1545,7 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   // record area = whatever follows the fixed part; a job whose record does not fit sets status bit 1
   // (needed: sum over selected chunks of rec_size(len) ~ 5*len + 1.6 KiB, twice where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
-  HMSE_FILL(w.counters, 0, 32 * sizeof(uint32_t), stream);
+  HMSE_FILL(w.counters, 0, N_CTR * sizeof(uint32_t), stream);
   HMSE_FILL(w.len_full, 0, n_sel * sizeof(uint32_t), stream);
   HMSE_FILL(w.len_delta, 0, n_sel * sizeof(uint32_t), stream);
   const uint32_t blocks = (uint32_t)((n_sel + 255) / 256);
@@ -1496,17 +1565,21 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   // persistent grids: small class 2 workgroups per CU, medium 1 per CU, big class a handful
   const uint64_t max_jobs = 2 * n_sel;  // (upper bound of any list)
   // big windows first (few, long jobs), then the LDS classes
-  auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 16 + c; };
+  auto sel = [&](int c) { a.jobs = w.lists + (size_t)c * w.list_stride; a.n_jobs = w.counters + c; a.counter = w.counters + 32 + c; };
+  // HMSE_DFL_DEBUG_SYNC=1 (diagnostics): wait after every launch and say which one returned — localises a kernel that does not finish
+  static const bool dbg_sync = getenv("HMSE_DFL_DEBUG_SYNC") != nullptr;
+  auto dbg = [&](int slot) { if (dbg_sync) { const hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "[hmse_l1_deflate] launch of slot %d finished (%d)\n", slot, (int)e); fflush(stderr); } };
+  a.prof_ctr = g_hmse_prof ? g_hmse_prof_ctr : nullptr; a.prof_slot = 0;
   // per class: the plain jobs, then the dictionary jobs (profile slots 8..13 and 18..23)
 #define HMSE_DFL_LAUNCH(LIST, SLOT, GRID, ...)                                                                      \
-  sel(LIST);                                                                                                         \
+  sel(LIST); a.prof_slot = (SLOT);                                                                                   \
   PROF_BEGIN(SLOT, stream);                                                                                          \
   if (launch_class<false, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
-  PROF_END(SLOT, stream);                                                                                            \
-  sel((int)dict_list(LIST));                                                                                         \
+  PROF_END(SLOT, stream); dbg(SLOT);                                                                                 \
+  sel((int)dict_list(LIST)); a.prof_slot = (SLOT) + 10;                                                              \
   PROF_BEGIN((SLOT) + 10, stream);                                                                                   \
   if (launch_class<true, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
-  PROF_END((SLOT) + 10, stream);
+  PROF_END((SLOT) + 10, stream); dbg((SLOT) + 10);
   HMSE_DFL_LAUNCH(3, 8 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
   HMSE_DFL_LAUNCH(2, 8 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
   HMSE_DFL_LAUNCH(8, 8 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
@@ -1524,14 +1597,42 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
       HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL));
       enc_attr = true;
     }
-    sel(6);
+    sel(6); a.prof_slot = 14;
     PROF_BEGIN(14, stream);
     l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);
-    PROF_END(14, stream);
-    sel(7);
+    PROF_END(14, stream); dbg(14);
+    sel(7); a.prof_slot = 15;
     PROF_BEGIN(15, stream);
     l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), E2::TOTAL, stream>>>(a);
-    PROF_END(15, stream);
+    PROF_END(15, stream); dbg(15);
+    HMSE_LAUNCH_CHECK();
+  }
+  // second pass (rule 7): FULL records of the chunks whose delta is larger than a fifth of the chunk (or could not be built):
+  // plain jobs per class on the redo lists, then their encodes (profile slots 24..29 and 30, 31); mostly empty lists
+  if (base) {
+    redo_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_delta, cfg->delta_max_ratio_pct, w.lists, w.list_stride,
+                                                        w.counters, n_dev);
+    HMSE_LAUNCH_CHECK();
+#define HMSE_DFL_REDO(LIST, SLOT, GRID, ...)                                                                         \
+  sel((int)redo_list(LIST)); a.prof_slot = (SLOT);                                                                   \
+  PROF_BEGIN(SLOT, stream);                                                                                          \
+  if (launch_class<false, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
+  PROF_END(SLOT, stream); dbg(SLOT);
+    HMSE_DFL_REDO(3, 24 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
+    HMSE_DFL_REDO(2, 24 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
+    HMSE_DFL_REDO(8, 24 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
+    HMSE_DFL_REDO(5, 24 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
+    HMSE_DFL_REDO(4, 24 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
+    HMSE_DFL_REDO(0, 24 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
+#undef HMSE_DFL_REDO
+    sel(21); a.prof_slot = 30;
+    PROF_BEGIN(30, stream);
+    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), EncLayout<256, 0, 12288>::TOTAL, stream>>>(a);
+    PROF_END(30, stream); dbg(30);
+    sel(22); a.prof_slot = 31;
+    PROF_BEGIN(31, stream);
+    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), EncLayout<256, 12288, 32768>::TOTAL, stream>>>(a);
+    PROF_END(31, stream); dbg(31);
     HMSE_LAUNCH_CHECK();
   }
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,

@@ -197,8 +197,8 @@ def lz_anchors(w: bytes, dl: int, buckets: dict) -> dict:
 
 
 def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
-    """Rules 1-2b: per chunk position the longest match among its `depth` nearest bucket predecessors; in a dictionary job a
-    position inside an anchor's full-length diagonal run takes that match when its walk leaves the chunk."""
+    """Rules 1-2c: per chunk position the longest match among its `depth` nearest bucket predecessors; in a dictionary job a
+    position inside an anchor's diagonal run (>= 16 bytes of it left) takes that match outright (no walk)."""
     dict_ = dict_[-32768:]
     w = dict_ + chunk
     t, dl = len(w), len(dict_)
@@ -226,24 +226,20 @@ def lz_matches(chunk: bytes, dict_: bytes = b"", depth: int = 32):
             m = cap if run >= 512 else (min(pa + run - p, cap) if pa + run > p else 0)
             if m > hint[0]:
                 hint = (m, p - d)
-        full = hint[0] >= 16 and hint[0] == cap
-        best, bdist, resolved = 3, 0, False
-        for q in reversed(members[max(0, r - depth):r]):   # nearest first
-            if p - q > 32768:
-                break
-            if full and q < dl:                            # leaving the chunk: the hinted match is taken
-                best, bdist, resolved = hint[0], p - hint[1], True
-                break
-            n = 0
-            while n < cap and w[q + n] == w[p + n]:
-                n += 1
-            if n > best:
-                best, bdist = n, p - q
-                if n == cap:
-                    resolved = True
-                    break
-        if full and not resolved:
+        best, bdist = 3, 0
+        if hint[0] >= 16:                                      # rule 2c: a hinted match is taken outright
             best, bdist = hint[0], p - hint[1]
+        else:
+            for q in reversed(members[max(0, r - depth):r]):   # nearest first
+                if p - q > 32768:
+                    break
+                n = 0
+                while n < cap and w[q + n] == w[p + n]:
+                    n += 1
+                if n > best:
+                    best, bdist = n, p - q
+                    if n == cap:
+                        break
         if best >= 4:
             mlen[p - dl], mdist[p - dl] = best, bdist
     return mlen, mdist
@@ -437,3 +433,17 @@ def deflate(chunk: bytes, dict_: bytes = b"", level: int = 9, chain_depth: int =
             b.put(lc[a], ll[a])
     b.put(lc[256], ll[256])
     return b.bytes()
+
+
+def deflate_record(chunk: bytes, base: bytes | None = None, level: int = 9, chain_depth: int = 0, delta_max_ratio_pct: int = 0):
+    """Rule 7 — FULL or DELTA (README.md:1328, 2175): with a base the dictionary stream comes first and IS the record
+    when it is at most a fifth of the chunk (the FULL stream is then never computed); a larger one is kept iff it nets savings over
+    FULL after the 8-byte DeltaChunk header.  Returns (stream, kind) with kind 0 = FULL, 2 = DELTA."""
+    if base is None:
+        return deflate(chunk, b"", level, chain_depth), 0
+    d = deflate(chunk, base, level, chain_depth)
+    gate = not (delta_max_ratio_pct and len(d) * 100 > delta_max_ratio_pct * len(chunk))
+    if gate and 5 * len(d) <= len(chunk):
+        return d, 2
+    f = deflate(chunk, b"", level, chain_depth)
+    return (d, 2) if gate and len(d) + 8 < len(f) else (f, 0)

@@ -321,6 +321,50 @@ def test_deflate_c_oracle_equals_python_restatement(orc):
     ml, md = orc.deflate_matches(text[:2500].encode() if isinstance(text, str) else text[:2500], orc.default_cfg())
     pl, pd = pyref.lz_matches(text[:2500], b"", 32)
     assert ml.tolist() == pl and md.tolist() == pd
+    # rule 2c (round 3): a position with a full-length diagonal hint takes it outright — also where the chunk itself holds a
+    # NEARER full-length candidate (a repeat inside the chunk), which rule 2b preferred
+    x = erng.integers(0, 256, 900, dtype=np.uint8).tobytes()
+    rep = x + x + base[:1500]
+    drep = bytearray(rep); drep[40] ^= 1; drep = bytes(drep)
+    want, got = orc.deflate(rep, orc.default_cfg(), drep), pyref.deflate(rep, drep)
+    assert want == got and _rt(got, drep) == rep
+    ml, md = orc.deflate_matches(rep, orc.default_cfg(), drep)
+    pl, pd = pyref.lz_matches(rep, drep, 32)
+    assert ml.tolist() == pl and md.tolist() == pd
+    p2 = 900 + 300                                      # inside the second copy of x: chunk candidate at distance 900, dictionary at len(drep)
+    assert int(ml[p2]) == 258 and int(md[p2]) == len(drep)
+
+
+def test_record_kind_rule_c_oracle_equals_python_restatement(orc):
+    """Rule 7 (README.md:1328, 2175): a delta of at most a fifth of the chunk is the record and FULL is never
+    computed; a larger one must net savings over FULL after the 8-byte header; the optional percentage gate refuses first.
+    orc_deflate_chunks against pyref.deflate_record on near-duplicates, an unrelated base, a base that does not help a highly
+    compressible chunk, and the 20 % gate."""
+    from oracle import pyref
+    rng = np.random.default_rng(17)
+    t1 = words_text(5000, seed=21).tobytes()
+    v1 = bytearray(t1); v1[700:705] = b"#####"; v1 = bytes(v1)
+    half = bytearray(t1); half[:2600] = rng.integers(97, 123, 2600, dtype=np.uint8).tobytes(); half = bytes(half)   # delta > a fifth, still a saving
+    zeros = bytes(6000)
+    chunks = [t1, v1, half, words_text(4000, seed=22).tobytes(), zeros, zeros[:5000] + b"\x01" * 10, rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()]
+    base = np.array([-1, 0, 0, 0, -1, 4, 3], np.int64)     # near-duplicate, half-duplicate, unrelated base, highly compressible + useless base, random + unrelated
+    data = np.frombuffer(b"".join(chunks), np.uint8)
+    cuts = np.concatenate([[0], np.cumsum([len(c) for c in chunks])]).astype(np.uint64)
+    kinds = set()
+    for pct in (0, 20, 60):
+        cfg = orc.default_cfg(delta_max_ratio_pct=pct)
+        out, off, kind = orc.deflate_chunks(data, cuts, cfg, None, base)
+        for k, c in enumerate(chunks):
+            b = chunks[base[k]] if base[k] >= 0 else None
+            st, kd = pyref.deflate_record(c, b, delta_max_ratio_pct=pct)
+            assert kd == int(kind[k]) and st == out[int(off[k]):int(off[k + 1])].tobytes(), (pct, k)
+            assert _rt(st, b if kd == 2 else None) == c
+            kinds.add((pct, k, kd))
+    assert (0, 1, 2) in kinds and (0, 2, 2) in kinds and (20, 2, 0) in kinds and (0, 3, 0) in kinds and (0, 6, 0) in kinds
+    # the quick accept really is taken without a look at FULL: a delta under a fifth of the chunk that does NOT beat FULL + 8
+    st, kd = pyref.deflate_record(zeros[:5000] + b"\x01" * 10, zeros)
+    full = pyref.deflate(zeros[:5000] + b"\x01" * 10)
+    assert kd == 2 and len(st) + 8 >= len(full)
 
 
 # ---------------------------------------------------------------- committed fixtures

@@ -22,7 +22,7 @@ sig = ops.l4_minhash(d, cuts, cfg, uniq)
 _, base = ops.l4_lsh(sig, cfg)
 ops.l1_deflate(d, cuts, cfg, uniq, base)
 torch.cuda.synchronize()
-buf = np.zeros(48, dtype=np.uint64)
+buf = np.zeros(96, dtype=np.uint64)
 lib.hmse_debug_deflate_stamps(buf.ctypes.data, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
@@ -30,7 +30,7 @@ lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
 ebuf = np.zeros(8, dtype=np.uint64)
 lib.hmse_debug_encode_stamps.argtypes = [C.c_void_p, C.c_int]
 lib.hmse_debug_encode_stamps(ebuf.ctypes.data, 0)
-names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match", "4 parse: stitch", "5 zero+hist", "6 trees", "7 rle+cl+decide", "8 codes", "9 emit+copy", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
+names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match: state machine", "4 parse: stitch", "5 tokens + histograms", "6 match: anchors + hinted positions", "7 -", "8 -", "9 record out", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
 lens = (cuts[1:] - cuts[:-1])[uniq]
 hb = base >= 0
 Tfull = lens
@@ -43,14 +43,14 @@ for ci_, nm in enumerate(("S", "S2", "SG", "SG2", "SG3", "B")):
     m_ = cls_ == ci_
     print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
-for c, cn in enumerate(["class S (T <= 9216)", "classes S2, SG (T <= 16000)", "classes SG2, SG3, B (dictionary jobs and big chunks)"]):
+for c, cn in enumerate(["plain S (T <= 9216)", "plain S2, SG (T <= 16000)", "plain SG2, SG3, B", "DICT S", "DICT S2, SG", "DICT SG2, SG3, B"]):
     row = buf[c * 16:(c + 1) * 16].astype(np.float64)
     trips, positions, jobs = row[13], row[14], row[15]
-    fetched, hinted, usable = row[6], row[7], row[8]
-    row[6:9] = 0
+    walked, usable = row[7], row[8]
+    row[7:9] = 0
     row[13:] = 0
-    if fetched:
-        print(cn, "dictionary-job positions of lane 0: %d with candidates, %.1f %% have a diagonal hint, %.1f %% a usable one" % (fetched, 100 * hinted / fetched, 100 * usable / fetched))
+    if walked:
+        print(cn, "positions walked by lane 0: %d, %.1f %% with a usable partial hint" % (walked, 100 * usable / walked))
     tot = row.sum()
     if tot == 0:
         continue

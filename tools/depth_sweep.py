@@ -53,7 +53,8 @@ def zlib_sizes(host, cuts, uniq, base):
         r = list(ex.map(one, range(len(uniq)), chunksize=256))
     full = np.array([x[0] for x in r], np.int64)
     delta = np.array([x[1] for x in r], np.int64)
-    stored = np.where((delta >= 0) & (delta + 8 < full), delta, full)
+    raw = np.array([int(cuts[int(c) + 1] - cuts[int(c)]) for c in uniq], np.int64)
+    stored = np.where((delta >= 0) & ((5 * delta <= raw) | (delta + 8 < full)), delta, full)
     return int(full.sum()), int(stored.sum())
 
 
