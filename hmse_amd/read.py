@@ -202,3 +202,94 @@ def read_manifest(m: Manifest, device, verify: bool = True) -> torch.Tensor:
     if verify and u and idx["sha256"].any():
         verify_digests(data, cuts, t(idx["sha256"][cmap["slot"]], torch.uint8))
     return data
+
+
+class StoreReader:
+    """Request-driven read (README.md:1444-1448 "Read Request (offset, len)" -> chunk map; 1621-1675 the three branches per
+    requested chunk; gate README.md:1329 "1000 random articles"): a store (or one manifest) is opened ONCE — blobs to HBM, record
+    headers parsed — and then serves byte ranges of the original corpus: chunk map -> the touched chunks -> their stored slots
+    (a POINTER names its target's) -> the transitive closure over DELTA dictionaries -> ONE hmse_l1_inflate over that subset
+    (dictionaries renumbered so that base < k) -> only the requested bytes are laid out -> SHA-256 of every touched chunk.
+    Nothing outside the closure is decoded."""
+
+    def __init__(self, store, device):
+        from .manifest import PTR_UNRESOLVED
+        shards = store.shards if isinstance(store, Store) else [store]
+        if any(((m.pointers["flags"] & PTR_UNRESOLVED) != 0).any() for m in shards):
+            raise ReadError("the store has unresolved cross-shard pointers: merge_manifests() its shards first")
+        self.dev = device
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dt).to(device)
+        sb = np.cumsum([0] + [len(m.index) for m in shards])
+        bb = np.cumsum([0] + [int(m.blob.size) for m in shards])
+        ps = [parse_manifest(m) for m in shards]
+        cat = lambda key, adj=None: np.concatenate([(p[key] if adj is None else adj(i, p)) for i, p in enumerate(ps)]) if ps else np.zeros(0, np.int64)
+        self.base = cat("base", lambda i, p: np.where(p["base"] >= 0, sb[p["base_shard"]] + p["base"], -1)).astype(np.int64)
+        self.kind = cat("kind").astype(np.uint8)
+        self.stream_off = cat("stream_off", lambda i, p: p["stream_off"] + bb[i]).astype(np.int64)
+        self.stream_len = cat("stream_len").astype(np.int64)
+        self.raw_len = cat("raw_len").astype(np.int64)
+        if len(self.base) and not (self.base < np.arange(len(self.base))).all():
+            raise ReadError("a DELTA record names a dictionary that is not an earlier record")
+        blobs = [t(m.blob, torch.uint8) for m in shards if m.blob.size]
+        self.blob = blobs[0] if len(blobs) == 1 else torch.cat(blobs) if blobs else torch.zeros(1, dtype=torch.uint8, device=device)
+        self.slot = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in shards]) \
+            if shards else np.zeros(0, np.int64)
+        lens = np.concatenate([m.chunk_map["raw_length"].astype(np.int64) for m in shards]) if shards else np.zeros(0, np.int64)
+        self.cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)          # chunk map: byte offset of every chunk
+        self.sha = np.concatenate([m.index["sha256"] for m in shards]) if shards else np.zeros((0, 32), np.uint8)
+        self.n_bytes = int(self.cuts[-1])
+        self.last = {}
+
+    def closure(self, slots: np.ndarray) -> np.ndarray:
+        """The stored slots needed to decode `slots`: themselves plus, transitively, the dictionaries of the DELTA records
+        among them (ascending: a dictionary always precedes its dependants)."""
+        need = np.unique(slots)
+        frontier = need
+        while frontier.size:
+            b = self.base[frontier]
+            b = np.unique(b[b >= 0])
+            frontier = b[~np.isin(b, need, assume_unique=True)]
+            if frontier.size:
+                need = np.union1d(need, frontier)
+        return need
+
+    def read_ranges(self, ranges, verify: bool = True) -> list:
+        """[(offset, length), ...] -> one uint8 tensor on the device per request (views into one buffer)."""
+        dev = self.dev
+        if not len(ranges):
+            return []
+        r = np.asarray(ranges, np.int64).reshape(-1, 2)
+        if (r[:, 0] < 0).any() or (r[:, 1] < 0).any() or (r[:, 0] + r[:, 1] > self.n_bytes).any():
+            raise ReadError("a requested range lies outside the stored corpus")
+        lo = np.searchsorted(self.cuts, r[:, 0], side="right") - 1                     # first chunk of every request
+        hi = np.searchsorted(self.cuts, r[:, 0] + r[:, 1], side="left")               # one past its last chunk
+        hi = np.maximum(hi, lo)
+        touched = np.zeros(len(self.cuts) - 1, bool)
+        for a, b in zip(lo, hi):
+            touched[a:b] = True
+        chunks = np.nonzero(touched)[0]
+        slots = self.slot[chunks]
+        need = self.closure(slots)                                                   # ascending global slot ids
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        b = self.base[need]
+        base_sel = np.where(b >= 0, np.searchsorted(need, np.maximum(b, 0)), -1)      # dictionaries renumbered into the subset
+        raw, raw_off, _ = ops.l1_inflate(self.blob, t(self.stream_off[need], torch.int64), t(self.kind[need], torch.uint8), t(base_sel, torch.int64),
+                                         t(self.raw_len[need], torch.int64), stream_len=t(self.stream_len[need], torch.int32))
+        # the touched chunks, back to back, from the slots that hold them (POINTER: the target's)
+        clen = self.cuts[chunks + 1] - self.cuts[chunks]
+        tcuts = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)
+        tcuts_d = t(tcuts, torch.int64)
+        buf = ops.read_assemble(tcuts_d, t(np.searchsorted(need, slots), torch.int64), raw_off, raw)
+        if verify and len(self.sha) and self.sha.any():
+            verify_digests(buf, tcuts_d, t(self.sha[slots], torch.uint8))
+        pos = np.searchsorted(chunks, lo)                                              # request -> its first chunk's place in buf
+        start = tcuts[np.minimum(pos, len(tcuts) - 1)] + (r[:, 0] - self.cuts[np.minimum(lo, len(self.cuts) - 2)])
+        self.last = {"requests": len(r), "chunks_touched": int(len(chunks)), "records_decoded": int(len(need)),
+                     "dictionaries_pulled_in": int(len(need) - len(np.unique(slots))), "bytes_decoded": int(self.raw_len[need].sum()),
+                     "bytes_requested": int(r[:, 1].sum())}
+        return [buf[int(s): int(s) + int(n)] for s, n in zip(start, r[:, 1])]
+
+
+def read_ranges(store, ranges, device, verify: bool = True) -> list:
+    """One-off form of StoreReader(store, device).read_ranges(ranges)."""
+    return StoreReader(store, device).read_ranges(ranges, verify)
