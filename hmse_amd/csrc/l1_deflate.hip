@@ -23,6 +23,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace dfl {
 
@@ -1471,12 +1472,13 @@ static Ws carve(void* ws, uint64_t n_sel) {
 template <bool DICT, int NT, int TCAP, int LCAP, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false>
 static int launch_class(Args a, uint32_t grid, hipStream_t stream) {
   using LY = Layout<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK, DICT>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL) != hipSuccess)
-      return HMSE_EHIP;
-    attr_set = true;
-  }
+  // (set once per instantiation; std::call_once: several host threads may enter the library at the same time)
+  static std::once_flag attr_once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK, DICT>, hipFuncAttributeMaxDynamicSharedMemorySize, LY::TOTAL);
+  });
+  if (attr_rc != hipSuccess) return HMSE_EHIP;
   l1_deflate_kernel<NT, TCAP, LCAP, LDSM, MDG, MLG, NOK, DICT><<<dim3(grid), dim3(NT), LY::TOTAL, stream>>>(a);
   return hipGetLastError() == hipSuccess ? HMSE_OK : HMSE_EHIP;
 }
@@ -1591,12 +1593,14 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   {
     using E1 = EncLayout<256, 0, 12288>;
     using E2 = EncLayout<256, 12288, 32768>;
-    static bool enc_attr = false;
-    if (!enc_attr) {
-      HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 0, 12288>, hipFuncAttributeMaxDynamicSharedMemorySize, E1::TOTAL));
-      HMSE_HIP(hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL));
-      enc_attr = true;
-    }
+    static std::once_flag enc_once;
+    static hipError_t enc_rc = hipSuccess;
+    std::call_once(enc_once, [] {
+      enc_rc = hipFuncSetAttribute((const void*)l1_encode_kernel<256, 0, 12288>, hipFuncAttributeMaxDynamicSharedMemorySize, E1::TOTAL);
+      if (enc_rc == hipSuccess)
+        enc_rc = hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL);
+    });
+    if (enc_rc != hipSuccess) return HMSE_EHIP;
     sel(6); a.prof_slot = 14;
     PROF_BEGIN(14, stream);
     l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);

@@ -17,6 +17,7 @@
 // The bit reader keeps a 64-bit window refilled from global memory; the output is re-read (match sources)
 // with agent-scope (L1-bypassing) loads after the wave's own stores have drained.
 #include "common.h"
+#include <atomic>
 
 namespace ifl {
 
@@ -993,7 +994,7 @@ static uint32_t* const g_ifl_trace = nullptr;
 #endif
 
 // 0 = choose by stream count, 1 = one stream per wavefront, 2 = one stream per lane
-static int g_ifl_mode = 0;
+static std::atomic<int> g_ifl_mode{0};   // process-wide knob (include/hmse.h); atomic: a host thread may flip it while another decodes
 constexpr uint64_t HMSE_INFLATE_WIDE_MIN = 49152;
 extern "C" int hmse_l1_inflate_mode(int mode) {
   if (mode < 0 || mode > 2) return HMSE_EINVAL;

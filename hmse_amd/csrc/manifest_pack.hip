@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void records_kernel(Args a) {
   uint8_t* dst = a.blob + o0;
   if (delta) {
     if (t == 0) {
-      const int64_t b = a.base[k];
+      const int64_t b = a.base ? a.base[k] : -1;   // (no base array: every DELTA record is flagged below)
       uint32_t blba = 0xFFFFFFFFu, blen = 0;
       if (b >= 0 && (uint64_t)b < k) { blba = (uint32_t)(a.rec_off[b] / a.lba_unit); blen = rec_len_of(a, (uint64_t)b); }
       else if (b == -2) { }               // dictionary stored on ANOTHER shard (global L4): header left unresolved (lba 0xFFFFFFFF,
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void records_kernel(Args a) {
   // ChunkIndex entry
   uint8_t* e = a.index + 40 * k;
   const uint64_t c = a.uniq_ids[k];
+  if (c >= a.n_chunks) { if (t == 0) atomicOr(a.status, 32u); return; }   // a stored-chunk id outside the shard
   if (t < 32) e[t] = a.digests ? a.digests[32 * c + t] : (uint8_t)0;
   if (t == 32) {
     const uint32_t lba = (uint32_t)(o0 / a.lba_unit);

@@ -113,7 +113,9 @@ def fetch_chunks(req: torch.Tensor, u_bases: list, data: torch.Tensor, cuts: tor
     wl, al = want.tolist(), asked.tolist()
     ids_in = torch.empty(sum(al), dtype=torch.int64, device=xdev)
     dist.all_to_all_single(ids_in, local_idx.to(xdev), output_split_sizes=al, input_split_sizes=wl, group=group)
-    # serve: the requested chunks' bytes, in request order
+    # serve: the requested chunks' bytes, in request order (ids come from other ranks: checked before they index anything)
+    if ids_in.numel() and (int(ids_in.min()) < 0 or int(ids_in.max()) >= uniq_ids.numel()):
+        raise ValueError(f"fetch_chunks: a peer asked for stored chunk {int(ids_in.max())} of {uniq_ids.numel()} (mismatched u_bases?)")
     cid = uniq_ids[ids_in.to(dev)]
     lens_out = cuts[cid + 1] - cuts[cid]
     out_cuts = torch.zeros(cid.numel() + 1, dtype=torch.int64, device=dev)
@@ -125,6 +127,8 @@ def fetch_chunks(req: torch.Tensor, u_bases: list, data: torch.Tensor, cuts: tor
     send_b = [oc[sum(al[:r + 1])] - oc[sum(al[:r])] for r in range(world)]
     li = lens_in.tolist()
     recv_b = [sum(li[sum(wl[:r]): sum(wl[:r + 1])]) for r in range(world)]
+    if (lens_in < 0).any() or (lens_in > 65536).any():
+        raise ValueError("fetch_chunks: a peer announced an impossible chunk length")
     got = torch.empty(sum(recv_b), dtype=torch.uint8, device=xdev)
     dist.all_to_all_single(got, payload.to(xdev), output_split_sizes=recv_b, input_split_sizes=send_b, group=group)
     return got.to(dev), lens_in.to(dev)
@@ -213,14 +217,17 @@ def ingest_shard(data: torch.Tensor, cfg: IngestConfig, seg_off: torch.Tensor | 
     return res
 
 
-def ingest_shards_local(shards: list, cfg: IngestConfig, global_l4: bool = False) -> list:
+def ingest_shards_local(shards: list, cfg: IngestConfig, global_l4: bool = False, seg_offs: list | None = None) -> list:
     """A sharded ingest with every shard on THIS GPU, one after the other: L2/L3 of every shard first, then the digest
     exchange as the all-gather would deliver it (concatenation in shard order), then L4/L1 per shard.  Each result is what
     the rank that owns the shard would hold after ingest_shard(distributed=True) — used to build and verify a multi-shard
     store without a second GPU, and by a single process that drives several shards."""
+    # (`seg_offs`: per shard its own segment offsets, e.g. document-aligned ones from hmse_amd.partition, instead of fixed seg_size runs)
     pre = []
-    for d in shards:
-        cuts = ops.l2_cdc(d, cfg) if cfg.layers & LAYER_L2 else fixed_cuts(d.numel(), cfg, ops.segment_offsets(d.numel(), cfg.seg_size, d.device))
+    for i, d in enumerate(shards):
+        so = seg_offs[i] if seg_offs is not None else None
+        cuts = ops.l2_cdc(d, cfg, so) if cfg.layers & LAYER_L2 else \
+            fixed_cuts(d.numel(), cfg, so if so is not None else ops.segment_offsets(d.numel(), cfg.seg_size, d.device))
         pre.append((cuts, ops.l3_sha256(d, cuts) if cfg.layers & LAYER_L3 else None))
     if not cfg.layers & LAYER_L3:
         return [ingest_shard(d, cfg, pre=p) for d, p in zip(shards, pre)]

@@ -189,11 +189,19 @@ def l4_lsh(sig: torch.Tensor, cfg: IngestConfig):
 
 
 def record_bytes(lens: torch.Tensor) -> torch.Tensor:
-    """hmse_l1_deflate_record_bytes() for a tensor of chunk lengths (<= 32768)."""
-    return (1296 + 4 * ((lens + 3) & ~3) + lens + 5 + 16 + 255) & ~255
+    """hmse_l1_deflate_record_bytes() for a tensor of chunk lengths (0 above 32768: such a chunk is never encoded)."""
+    return torch.where(lens <= 32768, (1296 + 4 * ((lens + 3) & ~3) + lens + 5 + 16 + 255) & ~255, torch.zeros_like(lens))
 
 
-DEFLATE_WS_LIMIT = 64 << 30   # bytes of per-job records one hmse_l1_deflate call may hold (l1_deflate splits a larger selection)
+DEFLATE_WS_LIMIT = 64 << 30   # upper bound of the per-job records one hmse_l1_deflate call may hold (l1_deflate splits a larger selection)
+
+
+def deflate_ws_limit(device) -> int:
+    """Record workspace one hmse_l1_deflate call may take: at most DEFLATE_WS_LIMIT and at most half of the HBM that is free
+    right now (cached blocks of the allocator count as free) — a resident corpus, streams and index then still fit beside it."""
+    free, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return max(256 << 20, min(DEFLATE_WS_LIMIT, (free + cached) // 2))
 
 
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
@@ -228,7 +236,7 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     c = cfg.to_c()
-    limit = DEFLATE_WS_LIMIT if ws_limit is None else int(ws_limit)
+    limit = deflate_ws_limit(dev) if ws_limit is None else int(ws_limit)
     if need <= limit:
         pieces = [(0, n_sel, need)]
         ids_all, base_all, by_id = chunk_ids, base, base_is_chunk_id

@@ -325,7 +325,9 @@ int hmse_stream_piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_by
  * DeltaChunk 8-byte header + delta data, 1312 pointer 8 B, 1448 per-chunk map, 1635-1669 chunk types).  Replaces the
  * reference's per-chunk "write chunk, insert (sha -> lba, len)" / "pointer record, refcount++" steps of the batch loop
  * (README.md:1542-1551) by one pass over a whole shard; the host only write()s the four arrays.
- *   streams/stream_off/kind/base/uniq_ids   the L1 outputs of the shard's n_unique stored chunks (base: slot index, -1 none)
+ *   streams/stream_off/kind/base/uniq_ids   the L1 outputs of the shard's n_unique stored chunks (base: slot index of the dictionary,
+ *             -1 none, -2 = a dictionary stored on ANOTHER shard (global L4): the DeltaChunk header is packed unresolved, base_lba
+ *             0xFFFFFFFF, and filled in when the shards' manifests are merged; base may be NULL when no record is a DELTA)
  *   digests DEVICE u8[n_chunks][32] or NULL, refcount DEVICE u32[n_chunks] or NULL, cuts DEVICE u64[n_chunks+1]
  *   first_occ DEVICE u64[n_chunks] GLOBAL index of each chunk's first occurrence (NULL: every chunk is its own);
  *             chunk_base = global index of this shard's chunk 0; shard / n_shards (<= 256); shard_bases DEVICE u64[n_shards]
@@ -339,7 +341,8 @@ int hmse_stream_piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_by
  *             A chunk whose first occurrence lives on another shard gets slot = that shard's LOCAL chunk index and an
  *             unresolved pointer record (target_lba 0xFFFFFFFF): the merge of the per-shard manifests fills them in.
  *   status    DEVICE u32[1]: bit0 record does not fit (slot, 32-bit lba or 16-bit length), bit1 DELTA without an earlier
- *             base, bit2 first occurrence is not a stored chunk, bit3 forward / unknown cross-shard target, bit4 pointer overflow
+ *             base, bit2 first occurrence is not a stored chunk, bit3 forward / unknown cross-shard target, bit4 pointer overflow,
+ *             bit5 a stored-chunk id (uniq_ids) outside the shard
  *   ws        hmse_workspace_bytes(HMSE_STAGE_MANIFEST_PACK, n_chunks, cfg)
  */
 int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream_off, const uint8_t* kind, const int64_t* base,

@@ -300,3 +300,43 @@ def test_distributed_ingest_world_size_1_runs_rccl(dev):
     for a, b in ((res.first_occ, ref.first_occ), (res.uniq_ids, ref.uniq_ids), (res.base, ref.base), (res.streams, ref.streams), (res.kind, ref.kind)):
         assert torch.equal(a, b)
     assert torch.equal(read.read_store(manifest.merge_manifests([manifest.build_manifest(res, 0, 1)]), dev), data)
+
+
+def test_document_aligned_two_shard_run_equals_oracle_with_the_same_segments(orc, dev):
+    """north_star "the corpus shards naturally by document": segments built from document boundaries (hmse_amd.partition),
+    whole documents dealt to two shards, every output equal to the oracle run over the same seg_off — and no chunk spans
+    a document boundary that is a segment boundary."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest, partition
+    cfg = IngestConfig(seg_size=256 << 10)
+    oc = orc.default_cfg(**asdict(cfg))
+    data = corpus.wiki_synth(5 << 20, seed=42)
+    data[(3 << 20): (3 << 20) + 400000] = data[100000: 500000]                   # duplicates across the two shards
+    t = torch.from_numpy(data).to(dev)
+    so = partition.document_seg_off(partition.document_starts(t), data.size, cfg.seg_size)
+    assert len(so) > 15 and (np.diff(so) <= cfg.seg_size).all() and (np.diff(so) % 4096 != 0).any()     # ragged segments
+    shards, seg_offs, want_cuts, want_dg, bounds = [], [], [], [], []
+    for a, b in partition.deal_segments(so, 2):
+        lo, hi, rel = partition.shard_seg_off(so, a, b, dev)
+        shards.append(t[lo:hi]); seg_offs.append(rel); bounds.append((lo, hi))
+        c = orc.cdc(data[lo:hi], oc, rel.cpu().numpy().astype(np.uint64))
+        want_cuts.append(c); want_dg.append(orc.sha256_chunks(data[lo:hi], c))
+    res = ingest.ingest_shards_local(shards, cfg, seg_offs=seg_offs)
+    fo, rc = orc.dedup(np.concatenate(want_dg))
+    base0 = 0
+    for r in range(2):
+        lo, hi = bounds[r]
+        n = len(want_cuts[r]) - 1
+        assert np.array_equal(res[r].cuts.cpu().numpy().astype(np.uint64), want_cuts[r])
+        assert np.isin(seg_offs[r].cpu().numpy()[1:], res[r].cuts.cpu().numpy()).all()     # every segment (document) boundary is a cut
+        fol = fo[base0: base0 + n]
+        assert np.array_equal(res[r].first_occ.cpu().numpy().astype(np.uint64), fol)
+        uniq = np.nonzero(fol == np.arange(base0, base0 + n))[0].astype(np.uint64)
+        sig = orc.minhash_chunks(data[lo:hi], want_cuts[r], oc, uniq)
+        _, base = orc.lsh(sig, oc)
+        out, off, kind = orc.deflate_chunks(data[lo:hi], want_cuts[r], oc, uniq, base)
+        assert np.array_equal(res[r].uniq_ids.cpu().numpy().astype(np.uint64), uniq)
+        assert np.array_equal(res[r].base.cpu().numpy(), base) and np.array_equal(res[r].kind.cpu().numpy(), kind)
+        assert np.array_equal(res[r].streams.cpu().numpy(), out)
+        base0 += n
+    assert int((res[1].first_occ < res[1].chunk_base).sum()) > 20                # cross-shard POINTERs

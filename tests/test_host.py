@@ -284,3 +284,33 @@ def test_store_with_dictionaries_in_other_shards(orc):
     hdr = m2.blob[(m2.index["lba"][rb["slot"]].astype(np.int64) * m2.lba_unit)[:, None] + np.arange(4)[None, :]].copy().view("<u4")[:, 0]
     assert np.array_equal(hdr, np.array([store.shards[int(s)].index["lba"][int(b)] for s, b in zip(rb["shard"], rb["base_slot"])], np.uint32))
     assert manifest.reconstruct(store) == data.tobytes()
+
+
+def test_document_aligned_segments_and_shards():
+    """hmse_amd.partition (north_star "shards naturally by document"): segments are runs of whole documents of at most seg_size
+    bytes, a longer document is cut every seg_size bytes, shards are runs of whole segments with balanced bytes."""
+    import torch
+    from hmse_amd import corpus, partition
+    data = corpus.wiki_synth(3 << 20, seed=42)
+    t = torch.from_numpy(data)
+    ds = partition.document_starts(t, slab=700001)          # slab boundaries inside the scan
+    assert ds[0] == 0 and (np.diff(ds) > 0).all() and len(ds) > 30
+    for p in ds[1:]:
+        assert bytes(data[p - 1: p + 2]) == b"\n= "
+    assert np.array_equal(ds, partition.document_starts(t))
+    seg = 256 << 10
+    so = partition.document_seg_off(ds, data.size, seg)
+    assert so[0] == 0 and so[-1] == data.size and (np.diff(so) > 0).all() and np.diff(so).max() <= seg
+    inner = so[1:-1]
+    assert np.isin(inner, ds).all()                         # every boundary is a document start (no document here is longer than seg)
+    assert np.diff(so)[:-1].min() > seg // 2                # and segments are well filled
+    # a document longer than seg_size is capped
+    so2 = partition.document_seg_off(np.array([0, 100, 5000000]), 6000000, 1 << 20)
+    assert so2.tolist() == [0, 100, 100 + (1 << 20), 100 + (2 << 20), 100 + (3 << 20), 100 + (4 << 20), 5000000, 6000000]
+    for world in (1, 2, 3, 8):
+        sh = partition.deal_segments(so, world)
+        assert sh[0][0] == 0 and sh[-1][1] == len(so) - 1 and all(a[1] == b[0] for a, b in zip(sh[:-1], sh[1:]))
+        sizes = [int(so[b] - so[a]) for a, b in sh]
+        assert sum(sizes) == data.size and max(sizes) - min(sizes) <= 2 * seg
+    lo, hi, rel = partition.shard_seg_off(so, *partition.deal_segments(so, 2)[1])
+    assert rel[0] == 0 and int(rel[-1]) == hi - lo and hi == data.size
