@@ -31,9 +31,8 @@ STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel
 # match kernels: slots 8..13 = plain jobs of a size class, 18..23 = its dictionary jobs (last template argument)
 STAGE_NAMES.update({slot: f"l1_deflate_kernel<{args},false>" for slot, args in _CLS.items()})
 STAGE_NAMES.update({slot + 10: f"l1_deflate_kernel<{args},true>" for slot, args in _CLS.items()})
-# second pass (rule 7 of the encoder definition): FULL records of the chunks whose delta is larger than a fifth of the chunk
-STAGE_NAMES.update({slot + 16: f"l1_deflate_kernel<{args},false> [second pass]" for slot, args in _CLS.items()})
-STAGE_NAMES.update({30: "l1_encode_kernel<256,0,12288> [second pass]", 31: "l1_encode_kernel<256,12288,32768> [second pass]"})
+# the encode kernels run twice per call: DELTA records (after the dictionary jobs; slots 30, 31), then FULL records (14, 15)
+STAGE_NAMES.update({30: "l1_encode_kernel<256,0,12288> [DELTA records]", 31: "l1_encode_kernel<256,12288,32768> [DELTA records]"})
 # what the SQ counters say about the kernels that can be "dominant" (profiles/r1/h_pmc_sq_counters_2GB.csv)
 VALU_NOTE = {"l4_minhash_kernel": "; SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 8 waves per SIMD = 1.1, i.e. the vector ALUs are "
                                   "saturated (9.25 instructions per (distinct shingle, seed) pair)"}
@@ -275,14 +274,11 @@ def main():
 
         by_class(ul[~hb], ul[~hb], 0)                # plain jobs
         by_class((ul + dl)[hb], ul[hb], 10)          # dictionary jobs (one token list: the DELTA record's)
-        for slot in (14, 15):
+        enc_slots = (14, 15, 30, 31)
+        tot_tok = sum(tokens.get(STAGE_NAMES[sl], 0) for sl in enc_slots) or 1
+        for slot in enc_slots:
             # encode kernel: token list read (counted), stream written (share of the stored bytes by token share)
-            alg[STAGE_NAMES[slot]] = int(4 * tokens.get(STAGE_NAMES[slot], 0))
-        tot_tok = sum(tokens.get(STAGE_NAMES[sl], 0) for sl in (14, 15)) or 1
-        for slot in (14, 15):
-            alg[STAGE_NAMES[slot]] += int(st["stored_bytes"] * tokens.get(STAGE_NAMES[slot], 0) / tot_tok)
-        for slot in list(range(24, 32)):             # second pass: token traffic only (its windows are not tracked per class here)
-            alg[STAGE_NAMES[slot]] = int(4 * tokens.get(STAGE_NAMES[slot], 0))
+            alg[STAGE_NAMES[slot]] = int(4 * tokens.get(STAGE_NAMES[slot], 0) + st["stored_bytes"] * tokens.get(STAGE_NAMES[slot], 0) / tot_tok)
     stage_roof = {}
     for name, k in kern.items():
         if name not in alg:

@@ -1237,12 +1237,12 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
 constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
 constexpr int NT_M = 1024, TCAP_SG3 = 32768;
 constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
-constexpr int N_LIST = 23;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); encode-kernel lists by
-                                // chunk length: 6 and 7; dictionary jobs per class: lists 9..14 (dict_list); second pass (FULL records of
-                                // chunks whose delta is no quick accept, rule 7): plain jobs 15..20 (redo_list), encode 21 and 22
+constexpr int N_LIST = 17;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); dictionary jobs per class:
+                                // lists 9..14 (dict_list); encode-kernel lists by chunk length: 6 and 7 (FULL records), 15 and 16 (DELTA
+                                // records).  The dictionary jobs run FIRST: the chunks whose delta is no quick accept (rule 7) then join
+                                // the plain lists for their FULL record, so every kernel symbol is launched once per call
 constexpr int N_CTR = 64;       // u32 counters: [c] = jobs in list c, [32 + c] = list c's cursor
 __host__ __device__ constexpr uint32_t dict_list(uint32_t c) { return c == 0 ? 9u : c == 4 ? 10u : c == 5 ? 11u : c == 8 ? 12u : c == 2 ? 13u : 14u; }
-__host__ __device__ constexpr uint32_t redo_list(uint32_t c) { return c == 0 ? 15u : c == 4 ? 16u : c == 5 ? 17u : c == 8 ? 18u : c == 2 ? 19u : 20u; }
 __host__ __device__ __forceinline__ uint32_t size_class(uint64_t T) {
   return T <= (uint64_t)TCAP_S ? 0u : T <= (uint64_t)TCAP_S2 ? 4u : T <= (uint64_t)TCAP_SG ? 5u : T <= (uint64_t)TCAP_SG2 ? 8u : T <= (uint64_t)TCAP_SG3 ? 2u : 3u;
 }
@@ -1291,10 +1291,11 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
   const bool enc_ok = in && L <= 32768;
   list_append(in && !hasb, size_class(L), (uint32_t)(k << 1), lists, list_stride, counts);
   list_append(in && hasb, dict_list(size_class(L + Dl)), (uint32_t)((k << 1) | 1u), lists, list_stride, counts);
-  list_append(enc_ok, L <= 12288 ? 6u : 7u, (uint32_t)((k << 1) | (hasb ? 1u : 0u)), lists, list_stride, counts);
+  list_append(enc_ok && !hasb, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append(enc_ok && hasb, L <= 12288 ? 15u : 16u, (uint32_t)((k << 1) | 1u), lists, list_stride, counts);
 }
 
-// second pass (rule 7): chunks with a base whose delta is no quick accept need their FULL record after all
+// rule 7: chunks with a base whose delta is no quick accept need their FULL record after all — they join the plain lists
 __global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                     const int64_t* __restrict__ base, uint64_t n_sel, const uint32_t* __restrict__ len_delta,
                                                     uint32_t pct, uint32_t* __restrict__ lists, uint64_t list_stride,
@@ -1307,8 +1308,8 @@ __global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ 
     L = cuts[c + 1] - cuts[c];
     redo = !delta_quick(len_delta[k], L, pct);
   }
-  list_append(redo, redo_list(size_class(L)), (uint32_t)(k << 1), lists, list_stride, counts);
-  list_append(redo && L <= 32768, L <= 12288 ? 21u : 22u, (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append(redo, size_class(L), (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append(redo && L <= 32768, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
 }
 
 // record sizes: FULL (+ DELTA when a base exists)
@@ -1572,27 +1573,11 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   static const bool dbg_sync = getenv("HMSE_DFL_DEBUG_SYNC") != nullptr;
   auto dbg = [&](int slot) { if (dbg_sync) { const hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "[hmse_l1_deflate] launch of slot %d finished (%d)\n", slot, (int)e); fflush(stderr); } };
   a.prof_ctr = g_hmse_prof ? g_hmse_prof_ctr : nullptr; a.prof_slot = 0;
-  // per class: the plain jobs, then the dictionary jobs (profile slots 8..13 and 18..23)
-#define HMSE_DFL_LAUNCH(LIST, SLOT, GRID, ...)                                                                      \
-  sel(LIST); a.prof_slot = (SLOT);                                                                                   \
-  PROF_BEGIN(SLOT, stream);                                                                                          \
-  if (launch_class<false, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
-  PROF_END(SLOT, stream); dbg(SLOT);                                                                                 \
-  sel((int)dict_list(LIST)); a.prof_slot = (SLOT) + 10;                                                              \
-  PROF_BEGIN((SLOT) + 10, stream);                                                                                   \
-  if (launch_class<true, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
-  PROF_END((SLOT) + 10, stream); dbg((SLOT) + 10);
-  HMSE_DFL_LAUNCH(3, 8 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
-  HMSE_DFL_LAUNCH(2, 8 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
-  HMSE_DFL_LAUNCH(8, 8 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
-  HMSE_DFL_LAUNCH(5, 8 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
-  HMSE_DFL_LAUNCH(4, 8 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
-  HMSE_DFL_LAUNCH(0, 8 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
-#undef HMSE_DFL_LAUNCH
-  // encode kernel: one 256-thread workgroup per job, two instantiations by chunk length (LDS image size)
+  // Order (rule 7): dictionary jobs -> their DELTA encodes -> redo_kernel (chunks whose delta is no quick accept join the plain
+  // lists) -> plain jobs -> FULL encodes.  Profile slots: plain 8..13, dictionary 18..23, encode FULL 14 / 15, encode DELTA 30 / 31.
+  using E1 = EncLayout<256, 0, 12288>;
+  using E2 = EncLayout<256, 12288, 32768>;
   {
-    using E1 = EncLayout<256, 0, 12288>;
-    using E2 = EncLayout<256, 12288, 32768>;
     static std::once_flag enc_once;
     static hipError_t enc_rc = hipSuccess;
     std::call_once(enc_once, [] {
@@ -1601,44 +1586,44 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
         enc_rc = hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL);
     });
     if (enc_rc != hipSuccess) return HMSE_EHIP;
-    sel(6); a.prof_slot = 14;
-    PROF_BEGIN(14, stream);
-    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);
-    PROF_END(14, stream); dbg(14);
-    sel(7); a.prof_slot = 15;
-    PROF_BEGIN(15, stream);
-    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), E2::TOTAL, stream>>>(a);
-    PROF_END(15, stream); dbg(15);
-    HMSE_LAUNCH_CHECK();
   }
-  // second pass (rule 7): FULL records of the chunks whose delta is larger than a fifth of the chunk (or could not be built):
-  // plain jobs per class on the redo lists, then their encodes (profile slots 24..29 and 30, 31); mostly empty lists
+#define HMSE_DFL_LAUNCH(DICT_, LIST, SLOT, GRID, ...)                                                               \
+  sel(LIST); a.prof_slot = (SLOT);                                                                                   \
+  PROF_BEGIN(SLOT, stream);                                                                                          \
+  if (launch_class<DICT_, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
+  PROF_END(SLOT, stream); dbg(SLOT);
+#define HMSE_DFL_ENCODE(LIST1, SLOT1, LIST2, SLOT2)                                                                  \
+  sel(LIST1); a.prof_slot = (SLOT1);                                                                                 \
+  PROF_BEGIN(SLOT1, stream);                                                                                         \
+  l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);        \
+  PROF_END(SLOT1, stream); dbg(SLOT1);                                                                               \
+  sel(LIST2); a.prof_slot = (SLOT2);                                                                                 \
+  PROF_BEGIN(SLOT2, stream);                                                                                         \
+  l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), E2::TOTAL, stream>>>(a);    \
+  PROF_END(SLOT2, stream); dbg(SLOT2);                                                                               \
+  HMSE_LAUNCH_CHECK();
   if (base) {
+    // big windows first (few, long jobs), then the LDS classes
+    HMSE_DFL_LAUNCH(true, (int)dict_list(3), 18 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
+    HMSE_DFL_LAUNCH(true, (int)dict_list(2), 18 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
+    HMSE_DFL_LAUNCH(true, (int)dict_list(8), 18 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
+    HMSE_DFL_LAUNCH(true, (int)dict_list(5), 18 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
+    HMSE_DFL_LAUNCH(true, (int)dict_list(4), 18 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
+    HMSE_DFL_LAUNCH(true, (int)dict_list(0), 18 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
+    HMSE_DFL_ENCODE(15, 30, 16, 31)
     redo_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_delta, cfg->delta_max_ratio_pct, w.lists, w.list_stride,
                                                         w.counters, n_dev);
     HMSE_LAUNCH_CHECK();
-#define HMSE_DFL_REDO(LIST, SLOT, GRID, ...)                                                                         \
-  sel((int)redo_list(LIST)); a.prof_slot = (SLOT);                                                                   \
-  PROF_BEGIN(SLOT, stream);                                                                                          \
-  if (launch_class<false, __VA_ARGS__>(a, (uint32_t)(max_jobs < (uint64_t)(GRID) ? max_jobs : (uint64_t)(GRID)), stream) != HMSE_OK) return HMSE_EHIP; \
-  PROF_END(SLOT, stream); dbg(SLOT);
-    HMSE_DFL_REDO(3, 24 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
-    HMSE_DFL_REDO(2, 24 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
-    HMSE_DFL_REDO(8, 24 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
-    HMSE_DFL_REDO(5, 24 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
-    HMSE_DFL_REDO(4, 24 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
-    HMSE_DFL_REDO(0, 24 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
-#undef HMSE_DFL_REDO
-    sel(21); a.prof_slot = 30;
-    PROF_BEGIN(30, stream);
-    l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), EncLayout<256, 0, 12288>::TOTAL, stream>>>(a);
-    PROF_END(30, stream); dbg(30);
-    sel(22); a.prof_slot = 31;
-    PROF_BEGIN(31, stream);
-    l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), EncLayout<256, 12288, 32768>::TOTAL, stream>>>(a);
-    PROF_END(31, stream); dbg(31);
-    HMSE_LAUNCH_CHECK();
   }
+  HMSE_DFL_LAUNCH(false, 3, 8 + 3, N_WG_B, NT_B, TCAP_B, LCAP_B, false)
+  HMSE_DFL_LAUNCH(false, 2, 8 + 2, 256, NT_M, TCAP_SG3, TCAP_SG3, true, true, true, true)
+  HMSE_DFL_LAUNCH(false, 8, 8 + 1, 512, NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true)
+  HMSE_DFL_LAUNCH(false, 5, 8 + 5, 512, NT_S, TCAP_SG, TCAP_SG, true, true, true)
+  HMSE_DFL_LAUNCH(false, 4, 8 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
+  HMSE_DFL_LAUNCH(false, 0, 8 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
+  HMSE_DFL_ENCODE(6, 14, 7, 15)
+#undef HMSE_DFL_LAUNCH
+#undef HMSE_DFL_ENCODE
   decide_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_full, w.len_delta,
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status, n_dev);
   HMSE_LAUNCH_CHECK();

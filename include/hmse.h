@@ -359,10 +359,10 @@ int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream_off, const
  * recorded events (a host sync — never call it inside a capture), adds their durations to the
  * stage's running total and returns it.  Off by default; not part of the data path.
  * Slots: the HMSE_STAGE_* ids (0..31); the six DEFLATE match-kernel size classes report in slots 8..13
- * (S, SG2, SG3, B, S2, SG), their dictionary jobs in 18..23, the second-pass FULL jobs (rule 7) in 24..29, and the two
- * encode-kernel instantiations in 14 and 15 (second pass: 30, 31) (hmse_amd/csrc/l1_deflate.hip).
+ * (S, SG2, SG3, B, S2, SG), their dictionary jobs in 18..23, and the two encode-kernel instantiations in 14 and 15 (FULL
+ * records) and 30 and 31 (DELTA records) (hmse_amd/csrc/l1_deflate.hip).
  * hmse_profile_counter(): work counted on the device while profiling is on — the DEFLATE match kernels add the TOKENS they
- * write to their slot (8..13, 18..23; second-pass FULL jobs 24..29), the encode kernels the tokens they read (14, 15, 30, 31):
+ * write to their slot (8..13, 18..23), the encode kernels the tokens they read (14, 15, 30, 31):
  * bench.py's algorithmic bytes come from these counts, not from an assumed token density.  A host sync; diagnostics only.
  */
 void hmse_profile_enable(int on);
