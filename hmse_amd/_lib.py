@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-HIP_LIB_PATH = os.path.join(_CSRC, "libhmse_hip.so")
+# HMSE_LIB_VARIANT=<tag> (diagnostics / A-B experiments only): load csrc/libhmse_hip_<tag>.so instead — e.g. the stamps or diag build
+HIP_LIB_PATH = os.path.join(_CSRC, "libhmse_hip" + ("_" + os.environ["HMSE_LIB_VARIANT"] if os.environ.get("HMSE_LIB_VARIANT") else "") + ".so")
 CORPUS_LIB_PATH = os.path.join(_CSRC, "libhmse_corpus.so")
 
 

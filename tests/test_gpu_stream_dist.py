@@ -192,3 +192,60 @@ def test_capacity_overflow_sets_the_sticky_status_and_drops_the_batch(dev, which
             assert torch.equal(s._cuts[n1 + 1:], guard["_cuts"][n1 + 1:])          # not one cut of the dropped batch was written
         if which == "stored":
             assert torch.equal(s._uniq[s.max_unique:], guard["_uniq"][s.max_unique:])
+
+
+def _gloo_rank(rank, world, port, pieces, cfg_kw, piece_bytes, out_q):
+    """One rank of a 2-process stream on GPU 0: the product loop (DistStreamIngest.push -> phase A -> all-gather of the rows over
+    gloo -> phase B) between real processes."""
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from hmse_amd import IngestConfig, stream_dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    cfg = IngestConfig(**cfg_kw)
+    total = sum(p.size for p in pieces[rank])
+    s = stream_dist.DistStreamIngest(cfg, max(total, 1), piece_bytes, dev, world, rank, graph=True)
+    for p in pieces[rank]:
+        s.push(torch.from_numpy(p))
+    res = s.finish()
+    out_q.put((rank, {nm: getattr(res, nm).cpu().numpy() for nm in NAMES + ("gidx",)}, res.n_global))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_over_gloo_equal_the_lock_step_emulation(dev):
+    """The N-rank control flow between REAL processes (two ranks sharing this GPU, exchange over gloo staged through host
+    memory — everything except RCCL itself): every rank's result equals what the one-process lock-step emulation computes."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from hmse_amd import IngestConfig, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    B, world = 4 << 20, 2
+    batches = [torch.from_numpy(data[a: a + B].copy()) for a in range(0, data.size, B)]
+    want = stream_dist.stream_shards_local(batches, cfg, world, dev, graph=False)
+    want = [{nm: getattr(r, nm).cpu().numpy() for nm in NAMES + ("gidx",)} for r in want]
+    pieces = [[], []]
+    for b in batches:
+        bd = stream_dist.deal_batch(b.numel(), world, cfg.seg_size)
+        for r in range(world):
+            pieces[r].append(b[bd[r]: bd[r + 1]].numpy().copy())
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from dataclasses import asdict
+    procs = [ctx.Process(target=_gloo_rank, args=(r, world, port, pieces, asdict(cfg), 2 << 20, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, arrs, n_global in got:
+        for nm in NAMES + ("gidx",):
+            assert np.array_equal(arrs[nm], want[rank][nm]), (rank, nm)
+    assert got[0][2] == got[1][2] == sum(len(w["gidx"]) for w in want)

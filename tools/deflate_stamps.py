@@ -22,7 +22,7 @@ sig = ops.l4_minhash(d, cuts, cfg, uniq)
 _, base = ops.l4_lsh(sig, cfg)
 ops.l1_deflate(d, cuts, cfg, uniq, base)
 torch.cuda.synchronize()
-buf = np.zeros(96, dtype=np.uint64)
+buf = np.zeros(144, dtype=np.uint64)
 lib.hmse_debug_deflate_stamps(buf.ctypes.data, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.l1_deflate(d, cuts, cfg, uniq, base); e1.record(); torch.cuda.synchronize()
@@ -44,7 +44,8 @@ for ci_, nm in enumerate(("S", "S2", "SG", "SG2", "SG3", "B")):
     print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
 for c, cn in enumerate(["plain S (T <= 9216)", "plain S2, SG (T <= 16000)", "plain SG2, SG3, B", "DICT S", "DICT S2, SG", "DICT SG2, SG3, B"]):
-    row = buf[c * 16:(c + 1) * 16].astype(np.float64)
+    row = buf[c * 24:(c + 1) * 24].astype(np.float64)
+    occ = row[16:22].copy(); row = row[:16]
     trips, positions, jobs = row[13], row[14], row[15]
     walked, usable = row[7], row[8]
     row[7:9] = 0
@@ -56,6 +57,9 @@ for c, cn in enumerate(["plain S (T <= 9216)", "plain S2, SG (T <= 16000)", "pla
         continue
     print(cn, "jobs %d  chunk positions %.1f M  trips of wavefront 0 through the matcher: %.1f per job = %.2f per 64 positions" % (jobs, positions / 1e6, trips / max(jobs, 1), 64 * trips / max(positions, 1)))
     print(cn, "total Mclk %.1f" % (tot / 1e6))
+    if trips:
+        print(cn, "matcher blocks per trip of wavefront 0: FETCH runs in %.0f %% of the trips with %.1f lanes, PROBE %.0f %% with %.1f lanes, EXTEND %.0f %% with %.1f lanes"
+              % (100 * occ[0] / trips, occ[1] / max(occ[0], 1), 100 * occ[2] / trips, occ[3] / max(occ[2], 1), 100 * occ[4] / trips, occ[5] / max(occ[4], 1)))
     for i, nm in enumerate(names):
         print("   %-18s %6.2f %%" % (nm, 100 * row[i] / tot))
 
