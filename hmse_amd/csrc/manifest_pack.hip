@@ -28,6 +28,7 @@ struct Args {
   const uint64_t* ptr_index;
   uint8_t* blob; uint64_t blob_bytes; uint8_t* index; uint8_t* chunk_map; uint8_t* pointers; uint64_t n_pointers;
   uint32_t* slot_of; uint32_t* status;
+  uint32_t any_target;   // HMSE_MANIFEST_ANY_SHARD_TARGET: a first occurrence may live on a LATER shard (multi-rank streams)
 };
 
 __device__ __forceinline__ uint32_t rec_len_of(const Args& a, uint64_t k) {
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void map_kernel(Args a) {
     if (is_ptr) { ptr_lba = (uint32_t)(a.rec_off[slot] / a.lba_unit); ptr_len = rec_len_of(a, slot); flags |= a.shard << 4; }
   } else {                                                         // ... on another shard: unresolved until the merge
     uint32_t r = 0;
-    if (!a.shard_bases || g >= a.chunk_base) { atomicOr(a.status, 8u); slot = 0; r = a.shard; }   // dedupe only ever points backwards
+    if (!a.shard_bases || (g >= a.chunk_base && !a.any_target)) { atomicOr(a.status, 8u); slot = 0; r = a.shard; }   // one-shot sharding: dedupe only ever points backwards
     else {
       for (uint32_t q = 1; q < a.n_shards; q++) if (a.shard_bases[q] <= g) r = q;
       slot = (uint32_t)(g - a.shard_bases[r]);
@@ -130,7 +131,20 @@ extern "C" int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream
                                   uint32_t lba_unit, const uint64_t* ptr_index, uint8_t* blob, uint64_t blob_bytes, void* index,
                                   void* chunk_map, void* pointers, uint64_t n_pointers, uint32_t* status, void* ws, size_t ws_bytes,
                                   void* stream_) {
+  return hmse_manifest_pack_ex(streams, stream_off, kind, base, uniq_ids, n_unique, digests, refcount, cuts, n_chunks, first_occ, chunk_base, shard,
+                               shard_bases, n_shards, 0u, rec_off, lba_unit, ptr_index, blob, blob_bytes, index, chunk_map, pointers, n_pointers, status,
+                               ws, ws_bytes, stream_);
+}
+
+extern "C" int hmse_manifest_pack_ex(const uint8_t* streams, const uint64_t* stream_off, const uint8_t* kind, const int64_t* base,
+                                     const uint64_t* uniq_ids, uint64_t n_unique, const uint8_t* digests, const uint32_t* refcount,
+                                     const uint64_t* cuts, uint64_t n_chunks, const uint64_t* first_occ, uint64_t chunk_base,
+                                     uint32_t shard, const uint64_t* shard_bases, uint32_t n_shards, uint32_t flags, const uint64_t* rec_off,
+                                     uint32_t lba_unit, const uint64_t* ptr_index, uint8_t* blob, uint64_t blob_bytes, void* index,
+                                     void* chunk_map, void* pointers, uint64_t n_pointers, uint32_t* status, void* ws, size_t ws_bytes,
+                                     void* stream_) {
   using namespace mfp;
+  if (flags & ~(uint32_t)HMSE_MANIFEST_ANY_SHARD_TARGET) return HMSE_EINVAL;
   if (!status || lba_unit == 0 || (lba_unit & (lba_unit - 1)) || n_shards == 0 || shard >= n_shards || n_shards > 256) return HMSE_EINVAL;
   if (n_chunks > 0xFFFFFFFEull || n_unique > n_chunks) return HMSE_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
@@ -147,7 +161,7 @@ extern "C" int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream
   a.digests = digests; a.refcount = refcount; a.cuts = cuts; a.n_chunks = n_chunks; a.first_occ = first_occ; a.chunk_base = chunk_base;
   a.shard = shard; a.shard_bases = shard_bases; a.n_shards = n_shards; a.rec_off = rec_off; a.lba_unit = lba_unit; a.ptr_index = ptr_index;
   a.blob = blob; a.blob_bytes = blob_bytes; a.index = (uint8_t*)index; a.chunk_map = (uint8_t*)chunk_map; a.pointers = (uint8_t*)pointers;
-  a.n_pointers = n_pointers; a.slot_of = (uint32_t*)ws; a.status = status;
+  a.n_pointers = n_pointers; a.slot_of = (uint32_t*)ws; a.status = status; a.any_target = flags & HMSE_MANIFEST_ANY_SHARD_TARGET;
   HMSE_FILL(a.slot_of, 0xFF, 4 * n_chunks, stream);
   PROF_BEGIN(HMSE_STAGE_MANIFEST_PACK, stream);
   if (n_unique) records_kernel<<<dim3((uint32_t)n_unique), dim3(256), 0, stream>>>(a);

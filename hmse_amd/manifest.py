@@ -28,6 +28,7 @@ DELTA_HDR_DTYPE = np.dtype([("base_lba", "<u4"), ("base_length", "<u2"), ("delta
 POINTER_DTYPE = np.dtype([("target_lba", "<u4"), ("target_length", "<u2"), ("flags", "<u2")])
 REMOTE_BASE_DTYPE = np.dtype([("slot", "<u4"), ("shard", "<u4"), ("base_slot", "<u4")])   # DELTA record `slot` of this shard: dictionary = record `base_slot` of `shard`
 MAP_DTYPE = np.dtype([("slot", "<u4"), ("raw_length", "<u2"), ("kind", "u1"), ("shard", "u1")])
+PIECE_DTYPE = np.dtype([("g0", "<u8"), ("n", "<u8")])   # multi-rank stream: a run of `n` consecutive local chunks whose global (stream-order) indices start at g0
 assert CHUNK_INDEX_DTYPE.itemsize == 40 and DELTA_HDR_DTYPE.itemsize == 8 and POINTER_DTYPE.itemsize == 8
 
 
@@ -43,34 +44,49 @@ class Manifest:
     n_shards: int = 1
     chunk_base: int = 0    # global index of this shard's chunk 0
     remote_bases: np.ndarray | None = None   # REMOTE_BASE_DTYPE: DELTA records whose dictionary is another shard's record (global L4)
+    pieces: np.ndarray | None = None         # PIECE_DTYPE: this shard's chunks in STREAM order (multi-rank streams: the shards interleave)
 
     def n_remote(self) -> int:
         return 0 if self.remote_bases is None else len(self.remote_bases)
 
+    def global_index(self) -> np.ndarray | None:
+        """Stream-order index of every local chunk (None: the store's order is (shard, local))."""
+        if self.pieces is None:
+            return None
+        return np.concatenate([np.arange(int(p["g0"]), int(p["g0"]) + int(p["n"]), dtype=np.int64) for p in self.pieces]) if len(self.pieces) else np.zeros(0, np.int64)
+
     def to_bytes(self) -> bytes:
         # version 2 = no record names a dictionary outside its own blob; version 3 appends the table of those that do
-        # (the 8-byte DeltaChunk header of README.md:2182-2189 has no room for a shard number)
+        # (the 8-byte DeltaChunk header of README.md:2182-2189 has no room for a shard number); version 4 (multi-rank stream)
+        # appends, behind that table, the shard's pieces: its chunks' places in the stream order
         nr = self.n_remote()
-        hdr = MAGIC + struct.pack("<IIQQQQIIQ", 3 if nr else 2, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size,
+        ver = 4 if self.pieces is not None else 3 if nr else 2
+        hdr = MAGIC + struct.pack("<IIQQQQIIQ", ver, self.lba_unit, len(self.index), len(self.chunk_map), len(self.pointers), self.blob.size,
                                   self.shard, self.n_shards, self.chunk_base)
-        tail = struct.pack("<Q", nr) + self.remote_bases.tobytes() if nr else b""
+        tail = struct.pack("<Q", nr) + (self.remote_bases.tobytes() if nr else b"") if (nr or ver == 4) else b""
+        if ver == 4:
+            tail += struct.pack("<Q", len(self.pieces)) + self.pieces.tobytes()
         return hdr + self.index.tobytes() + self.chunk_map.tobytes() + self.pointers.tobytes() + self.blob.tobytes() + tail
 
     @staticmethod
     def from_bytes(b: bytes) -> "Manifest":
         assert b[:8] == MAGIC
         ver, unit, nu, nc, npt, nb, shard, n_shards, cbase = struct.unpack_from("<IIQQQQIIQ", b, 8)
-        assert ver in (2, 3)
+        assert ver in (2, 3, 4)
         o = 8 + struct.calcsize("<IIQQQQIIQ")
         idx = np.frombuffer(b, CHUNK_INDEX_DTYPE, nu, o); o += nu * 40
         cmap = np.frombuffer(b, MAP_DTYPE, nc, o); o += nc * 8
         ptr = np.frombuffer(b, POINTER_DTYPE, npt, o); o += npt * 8
         blob = np.frombuffer(b, np.uint8, nb, o); o += nb
-        remote = None
-        if ver == 3:
+        remote = pieces = None
+        if ver >= 3:
             (nr,) = struct.unpack_from("<Q", b, o)
-            remote = np.frombuffer(b, REMOTE_BASE_DTYPE, nr, o + 8)
-        return Manifest(unit, idx, cmap, ptr, blob, shard, n_shards, cbase, remote)
+            remote = np.frombuffer(b, REMOTE_BASE_DTYPE, nr, o + 8) if nr else None
+            o += 8 + nr * REMOTE_BASE_DTYPE.itemsize
+        if ver == 4:
+            (npc,) = struct.unpack_from("<Q", b, o)
+            pieces = np.frombuffer(b, PIECE_DTYPE, npc, o + 8)
+        return Manifest(unit, idx, cmap, ptr, blob, shard, n_shards, cbase, remote, pieces)
 
     def nbytes(self) -> int:
         return 8 + struct.calcsize("<IIQQQQIIQ") + self.index.nbytes + self.chunk_map.nbytes + self.pointers.nbytes + self.blob.nbytes
@@ -79,7 +95,7 @@ class Manifest:
 PTR_UNRESOLVED = 0x8000   # pointer-record flag: the target lives on another shard and its lba is filled in by merge_manifests
 
 
-def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
+def pack_manifest_device(res, shard: int = 0, n_shards: int = 1, any_target: bool = False):
     """The shard's packed records in HBM: (lba_unit, blob u8[], index u8[u,40], chunk_map u8[n,8], pointers u8[p,8]).
     ONE pass of GPU kernels over the ShardResult (hmse_manifest_pack, hmse_amd/csrc/manifest_pack.hip) plus two prefix
     sums for the record and pointer positions; the only host sync reads the two output sizes."""
@@ -109,7 +125,7 @@ def pack_manifest_device(res, shard: int = 0, n_shards: int = 1):
     index = torch.empty((u, 40), dtype=torch.uint8, device=dev)
     cmap = torch.empty((n, 8), dtype=torch.uint8, device=dev)
     ptrs = torch.empty((n_ptr, 8), dtype=torch.uint8, device=dev)
-    ops.manifest_pack(res, shard, n_shards, getattr(res, "shard_bases", None), rec_off, unit, ptr_index, blob, index, cmap, ptrs)
+    ops.manifest_pack(res, shard, n_shards, getattr(res, "shard_bases", None), rec_off, unit, ptr_index, blob, index, cmap, ptrs, any_target=any_target)
     return unit, blob, index, cmap, ptrs
 
 
@@ -136,10 +152,11 @@ def build_manifest(res, shard: int = 0, n_shards: int = 1) -> Manifest:
     """pack_manifest_device() + one device -> host copy per array: the host receives four finished arrays and only has to
     write() them.  A chunk whose first occurrence lives on another shard (sharded ingest) becomes a POINTER
     with an unresolved pointer record; merge_manifests() resolves those once every shard's manifest exists."""
-    unit, blob, index, cmap, ptrs = pack_manifest_device(res, shard, n_shards)
+    pieces = getattr(res, "pieces", None)           # a multi-rank stream's shard (stream_dist.store_results): stream-order table,
+    unit, blob, index, cmap, ptrs = pack_manifest_device(res, shard, n_shards, any_target=pieces is not None)   # targets on any shard
     host = lambda t, dt: np.frombuffer(t.cpu().numpy().tobytes(), dt)
     return Manifest(unit, host(index, CHUNK_INDEX_DTYPE), host(cmap, MAP_DTYPE), host(ptrs, POINTER_DTYPE), blob.cpu().numpy(),
-                    shard, n_shards, int(res.chunk_base), remote_base_table(res))
+                    shard, n_shards, int(res.chunk_base), remote_base_table(res), pieces)
 
 
 @dataclass
@@ -176,7 +193,7 @@ def merge_manifests(parts: list) -> Store:
         pidx = np.nonzero(is_ptr)[0][unresolved]                     # chunk index of every unresolved pointer
         for r in np.unique(cmap["shard"][pidx]):
             t = parts[int(r)]
-            assert int(r) < m.shard, "dedupe only ever points backwards"
+            assert int(r) < m.shard or (m.pieces is not None and int(r) != m.shard), "dedupe only ever points backwards (the shards of a stream interleave: any other shard)"
             sel = pidx[cmap["shard"][pidx] == r]
             tgt_chunk = cmap["slot"][sel].astype(np.int64)           # the target shard's LOCAL chunk index
             assert (tgt_chunk < len(t.chunk_map)).all() and (t.chunk_map["kind"][tgt_chunk] != KIND_POINTER).all(), \
@@ -202,8 +219,22 @@ def merge_manifests(parts: list) -> Store:
                 h["base_lba"] = t.index["lba"][sel["base_slot"]]; h["base_length"] = t.index["length"][sel["base_slot"]]
                 h["delta_length"] = m.index["length"][sel["slot"]] - 8
                 blob[pos[:, None] + np.arange(8)[None, :]] = np.frombuffer(h.tobytes(), np.uint8).reshape(len(sel), 8)
-        out.append(Manifest(m.lba_unit, m.index, cmap, ptrs, blob, m.shard, m.n_shards, m.chunk_base, m.remote_bases))
+        out.append(Manifest(m.lba_unit, m.index, cmap, ptrs, blob, m.shard, m.n_shards, m.chunk_base, m.remote_bases, m.pieces))
     return Store(out)
+
+
+def stream_order(shards: list) -> np.ndarray | None:
+    """A store written by a multi-rank STREAM keeps its chunks per shard, but the original bytes are the chunks in stream
+    order (batch, rank, local): the permutation from stream position to the (shard, local)-concatenated chunk list, or None for
+    a store whose order is (shard, local)."""
+    if not shards or all(m.pieces is None for m in shards):
+        return None
+    assert all(m.pieces is not None for m in shards), "every shard of a stream store carries its pieces"
+    g = np.concatenate([m.global_index() for m in shards])
+    assert len(g) == sum(len(m.chunk_map) for m in shards)
+    perm = np.argsort(g, kind="stable")
+    assert np.array_equal(g[perm], np.arange(len(g))), "the shards' pieces must tile the stream"
+    return perm
 
 
 def reconstruct(m) -> bytes:
@@ -245,4 +276,8 @@ def reconstruct(m) -> bytes:
         cache[(r, slot)] = out
         return out
 
-    return b"".join(raw_of(int(c["shard"]), int(c["slot"])) for s in shards for c in s.chunk_map)
+    chunks = [(int(c["shard"]), int(c["slot"])) for s in shards for c in s.chunk_map]
+    perm = stream_order(shards)
+    if perm is not None:
+        chunks = [chunks[int(i)] for i in perm]
+    return b"".join(raw_of(r, slot) for r, slot in chunks)

@@ -339,7 +339,7 @@ def read_assemble(cuts: torch.Tensor, slot_of_chunk: torch.Tensor, raw_off: torc
 
 
 def manifest_pack(res, shard: int, n_shards: int, shard_bases, rec_off: torch.Tensor, lba_unit: int, ptr_index: torch.Tensor,
-                  blob: torch.Tensor, index: torch.Tensor, chunk_map: torch.Tensor, pointers: torch.Tensor) -> None:
+                  blob: torch.Tensor, index: torch.Tensor, chunk_map: torch.Tensor, pointers: torch.Tensor, any_target: bool = False) -> None:
     """hmse_manifest_pack over a ShardResult: blob, ChunkIndex table, chunk map and pointer records written in place.
     README.md:1263-1270, 2182-2189, 1312, 1448."""
     for t, nm in ((res.cuts, "cuts"), (res.uniq_ids, "uniq_ids"), (res.streams, "streams"), (res.stream_off, "stream_off"), (res.kind, "kind"),
@@ -358,9 +358,9 @@ def manifest_pack(res, shard: int, n_shards: int, shard_bases, rec_off: torch.Te
         if sb.numel() != n_shards:
             raise HmseError(-1, "manifest_pack: one chunk base per shard")
     keep = blob if blob.numel() else torch.empty(1, dtype=torch.uint8, device=dev)
-    rc = _lib.hip_lib().hmse_manifest_pack(_ptr(res.streams), _ptr(res.stream_off), _ptr(res.kind), _ptr(base), _ptr(res.uniq_ids),
+    rc = _lib.hip_lib().hmse_manifest_pack_ex(_ptr(res.streams), _ptr(res.stream_off), _ptr(res.kind), _ptr(base), _ptr(res.uniq_ids),
                                           res.uniq_ids.numel(), _ptr(res.digests), _ptr(res.refcount), _ptr(res.cuts), n, _ptr(res.first_occ),
-                                          int(res.chunk_base), shard, _ptr(sb), n_shards, _ptr(rec_off), lba_unit, _ptr(ptr_index), _ptr(keep),
+                                          int(res.chunk_base), shard, _ptr(sb), n_shards, 1 if any_target else 0, _ptr(rec_off), lba_unit, _ptr(ptr_index), _ptr(keep),
                                           blob.numel(), _ptr(index), _ptr(chunk_map), _ptr(pointers) if pointers.numel() else None,
                                           pointers.shape[0], _ptr(status), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_manifest_pack")

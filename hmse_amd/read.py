@@ -176,6 +176,10 @@ def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
     slot_g = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in store.shards]) \
         if store.shards else np.zeros(0, np.int64)
     lens = np.concatenate([m.chunk_map["raw_length"].astype(np.int64) for m in store.shards]) if store.shards else np.zeros(0, np.int64)
+    from .manifest import stream_order
+    perm = stream_order(store.shards)          # a multi-rank stream's store: the original bytes are the chunks in stream order
+    if perm is not None:
+        slot_g, lens = slot_g[perm], lens[perm]
     cuts = torch.zeros(len(lens) + 1, dtype=torch.int64, device=device)
     torch.cumsum(t(lens, torch.int64), 0, out=cuts[1:])
     data = ops.read_assemble(cuts, t(slot_g, torch.int64), raw_off_all, raw_all)
@@ -235,6 +239,10 @@ class StoreReader:
         self.slot = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in shards]) \
             if shards else np.zeros(0, np.int64)
         lens = np.concatenate([m.chunk_map["raw_length"].astype(np.int64) for m in shards]) if shards else np.zeros(0, np.int64)
+        from .manifest import stream_order
+        perm = stream_order(shards)             # a multi-rank stream's store: requests address the stream, whose chunks interleave the shards
+        if perm is not None:
+            self.slot, lens = self.slot[perm], lens[perm]
         self.cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)          # chunk map: byte offset of every chunk
         self.sha = np.concatenate([m.index["sha256"] for m in shards]) if shards else np.zeros((0, 32), np.uint8)
         self.n_bytes = int(self.cuts[-1])

@@ -254,3 +254,56 @@ def stream_shards_local(batches: list, cfg: IngestConfig, world: int, device, pi
             s.encode_piece(n, rows)
             s.n_bytes += n
     return [s.finish() for s in ranks]
+
+
+def store_results(results: list, only: int | None = None) -> list:
+    """The ranks' results of a multi-rank stream in the STORE numbering — what manifest.build_manifest needs to write one manifest
+    per rank that manifest.merge_manifests can join: chunk indices become (shard, local) = vbase[shard] + local, so every shard's
+    chunks are contiguous again (`chunk_base`, `shard_bases`), `first_occ` is translated, and `pieces` records where the shard's
+    chunks sit in the STREAM order (the shards interleave; the reader restores the stream from it).  A first occurrence may live on
+    a later-numbered shard (HMSE_MANIFEST_ANY_SHARD_TARGET).  `results`: every rank's DistStreamIngest.finish(), in rank order
+    (stream_shards_local returns exactly that; N processes all-gather their `gidx` first — gather_global_index — and convert
+    `only` their own)."""
+    import dataclasses
+
+    import numpy as np
+    from .manifest import PIECE_DTYPE
+    dev = results[0].cuts.device
+    counts = [int(r.gidx.numel()) for r in results]
+    vbase = [sum(counts[:i]) for i in range(len(results))]
+    n_global = results[0].n_global
+    to_store = torch.full((n_global,), -1, dtype=torch.int64, device=dev)
+    for r, vb in zip(results, vbase):
+        to_store[r.gidx] = torch.arange(vb, vb + r.gidx.numel(), dtype=torch.int64, device=dev)
+    if bool((to_store < 0).any()):
+        raise ValueError("store_results: the ranks' chunks do not tile the stream")
+    out = []
+    for rank, (r, vb) in enumerate(zip(results, vbase)):
+        if only is not None and rank != only:
+            out.append(None)
+            continue
+        g = r.gidx.cpu().numpy()
+        starts = np.nonzero(np.diff(g, prepend=g[:1] - 2) != 1)[0] if len(g) else np.zeros(0, np.int64)
+        ends = np.append(starts[1:], len(g))
+        pieces = np.zeros(len(starts), PIECE_DTYPE)
+        pieces["g0"] = g[starts] if len(g) else 0
+        pieces["n"] = ends - starts
+        rr = dataclasses.replace(r, first_occ=to_store[r.first_occ], chunk_base=vb, shard_bases=list(vbase))
+        rr.gidx, rr.pieces = r.gidx, pieces
+        out.append(rr)
+    return out
+
+
+def gather_global_index(res, group=None):
+    """N processes: every rank's `gidx` (all-gather; 8 B per chunk), as the list store_results() wants — only the index maps travel,
+    the other ranks' results stay where they are: returns light stand-ins carrying (gidx, n_global) for the other ranks."""
+    import types
+    import torch.distributed as dist
+    from .ingest import gather_rows
+    allg, base, total, bases = gather_rows(res.gidx.reshape(-1, 1), group)
+    world = dist.get_world_size(group)
+    bases = list(bases) + [total]
+    out = []
+    for r in range(world):
+        out.append(res if r == dist.get_rank(group) else types.SimpleNamespace(gidx=allg[bases[r]: bases[r + 1], 0], n_global=res.n_global, cuts=res.cuts))
+    return out

@@ -352,6 +352,19 @@ int hmse_manifest_pack(const uint8_t* streams, const uint64_t* stream_off, const
                        uint32_t lba_unit, const uint64_t* ptr_index, uint8_t* blob, uint64_t blob_bytes, void* index,
                        void* chunk_map, void* pointers, uint64_t n_pointers, uint32_t* status, void* ws, size_t ws_bytes,
                        void* stream);
+/* With options: HMSE_MANIFEST_ANY_SHARD_TARGET — a chunk's first occurrence may live on ANY other shard, also a later one.  The
+ * shards of a multi-rank stream interleave in stream order (hmse_stream_piece_encode), so the rank that met a chunk first is not
+ * always the lower-numbered one; the caller passes first_occ / chunk_base / shard_bases in the STORE numbering (shard, local
+ * index) — hmse_amd/stream_dist.py::store_results.  Without the flag a forward target is an error (status bit3), as in a
+ * one-shot sharded ingest, where dedupe only ever points backwards. */
+enum { HMSE_MANIFEST_ANY_SHARD_TARGET = 1u };
+int hmse_manifest_pack_ex(const uint8_t* streams, const uint64_t* stream_off, const uint8_t* kind, const int64_t* base,
+                          const uint64_t* uniq_ids, uint64_t n_unique, const uint8_t* digests, const uint32_t* refcount,
+                          const uint64_t* cuts, uint64_t n_chunks, const uint64_t* first_occ, uint64_t chunk_base,
+                          uint32_t shard, const uint64_t* shard_bases, uint32_t n_shards, uint32_t flags,
+                          const uint64_t* rec_off, uint32_t lba_unit, const uint64_t* ptr_index, uint8_t* blob,
+                          uint64_t blob_bytes, void* index, void* chunk_map, void* pointers, uint64_t n_pointers,
+                          uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Diagnostics (bench.py's roofline leg): when enabled, every entry point brackets its DOMINANT

@@ -109,6 +109,22 @@ def test_multi_rank_stream_equals_oracle(orc, dev, world, graph):
     back = read.reconstruct_shards(res, verify=True)
     for r in range(world):
         assert np.array_equal(back[r].cpu().numpy(), want[r]["data"]), r
+    # ... and the STORE: one manifest per rank in the store numbering (first occurrences on any other shard, also later ones),
+    # merged; the readers restore the STREAM order from the shards' pieces — host zlib verifier, whole-store GPU read, ranges
+    from hmse_amd import manifest
+    sr = stream_dist.store_results(res)
+    parts = [manifest.Manifest.from_bytes(manifest.build_manifest(sr[r], r, world).to_bytes()) for r in range(world)]
+    assert all(p.pieces is not None and len(p.pieces) >= 3 for p in parts)
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    fwd = sum(int((p.chunk_map["shard"][p.chunk_map["kind"] == 1] > p.shard).sum()) for p in store.shards)
+    assert fwd > 10                                                  # POINTERs to LATER-numbered shards exist
+    assert manifest.reconstruct(store) == data.tobytes()
+    assert np.array_equal(read.read_store(store, dev).cpu().numpy(), data)
+    rd = read.StoreReader(store, dev)
+    rng = np.random.default_rng(3)
+    off = rng.integers(0, data.size - 50000, 200); ln = rng.integers(1, 50000, 200)
+    for o, n, g in zip(off, ln, rd.read_ranges(list(zip(off.tolist(), ln.tolist())))):
+        assert np.array_equal(g.cpu().numpy(), data[o: o + n]), (o, n)
 
 
 def test_one_batch_is_the_sharded_one_shot_ingest_and_one_rank_is_the_single_rank_stream(dev):
