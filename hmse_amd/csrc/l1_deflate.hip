@@ -355,7 +355,7 @@ __device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint3
 
 #ifdef HMSE_DFL_STAMPS
 // diagnostic build only: per-phase shader-clock totals of thread 0, summed over jobs and workgroups
-__device__ unsigned long long g_dfl_stamps[6][16];   // [size group + 3 * dictionary jobs][phase]
+__device__ unsigned long long g_dfl_stamps[6][24];   // [size group + 3 * dictionary jobs][phase]
 __device__ unsigned long long g_enc_stamps[8];   // encode kernel: clocks of thread 0 per phase (0 load, 1 trees, 2 rle+cl+decide, 3 codes, 4 emit, 5 copy-out), [7] records
 #define STAMP(i) do { if (t == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
 #else
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
-  unsigned long long stamp_acc[16] = {0}, stamp_last = clock64();
+  unsigned long long stamp_acc[24] = {0}, stamp_last = clock64();
 #endif
 
   for (;;) {
@@ -510,9 +510,10 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // step's increments, complete at the first barrier) sits in front of the second one, so that barrier also separates
       // it from the next step's increments; the in-place rewrite of this step's slots [before, after) then runs beside the
       // next step's scatter into slots >= after.
-      uint32_t q = t, h = 0, before = 0;
+      // (filter byte of a position: low nibble of its byte 4 | four more bits of its hash product, see the matcher's `rejects`)
+      uint32_t q = t, h = 0, before = 0, hx = 0;
       bool act = q < nh;
-      if (act) { h = hash4(ld32(W + q)); before = cur_get(cur, h); }
+      if (act) { hx = ld32(W + q) * 0x9E3779B1u; h = hx >> (32 - HB); before = cur_get(cur, h); }
       __syncthreads();
       for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
         if (act) S[cur_inc(cur, h)] = (uint16_t)q;
@@ -524,11 +525,11 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         }
         const uint32_t qn = q0 + NT + t;
         const bool actn = qn < nh;
-        uint32_t hn = 0, beforen = 0;
-        if (actn) { hn = hash4(ld32(W + qn)); beforen = cur_get(cur, hn); }
+        uint32_t hn = 0, beforen = 0, hxn = 0;
+        if (actn) { hxn = ld32(W + qn) * 0x9E3779B1u; hn = hxn >> (32 - HB); beforen = cur_get(cur, hn); }
         __syncthreads();
-        if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = W[q + 4]; }
-        q = qn; act = actn; h = hn; before = beforen;
+        if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = (uint8_t)((W[q + 4] & 0x0Fu) | ((hx >> 12) & 0xF0u)); }
+        q = qn; act = actn; h = hn; before = beforen; hx = hxn;
       }
       __syncthreads();  // cursor h now = end of bucket h
     }
@@ -638,6 +639,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
+      uint32_t pkey = 0;   // classes with the filter array: this position's own filter byte
+      // Can candidate with filter byte kb be skipped without a window read?  Filter array classes: kb = (byte 4 & 15) | 4 further
+      // bits of the hash product << 4 — a candidate whose high nibble differs holds a DIFFERENT 4-gram in the same bucket
+      // (a quarter of all candidates on text) and can never match; one whose low nibble differs has a different byte 4 and cannot
+      // beat a best >= 4.  Class SG2/SG3 (no array): kb = the candidate's byte 4, read from the window.
+      auto rejects = [&](uint32_t kb) -> bool {
+        if constexpr (NOK) return best >= 4 && kb != (pw1 & 0xFFu);
+        else { const uint32_t x = kb ^ pkey; return (x & 0xF0u) != 0 || (best >= 4 && (x & 0x0Fu) != 0); }
+      };
       // dictionary jobs: this wavefront's window of pending work ranks (wave-uniform)
       uint64_t wq_mask = 0; uint32_t wq_base = 0; bool wq_done = false;
       const uint32_t nh_s = uni32(nh);
@@ -648,7 +658,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
         kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
         ld64a(W, p, pw0, pw1);
-        const uint32_t h = hash4(pw0);
+        const uint32_t hxp = pw0 * 0x9E3779B1u;
+        const uint32_t h = hxp >> (32 - HB);
+        pkey = (pw1 & 0x0Fu) | ((hxp >> 12) & 0xF0u);
         const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
         maxlen = (T - p) < MAXM ? (T - p) : MAXM;
         kmax = i - lo;
@@ -730,6 +742,14 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           }
         }
         if (uni64(__ballot(st != DONE)) == 0) break;
+#ifdef HMSE_DFL_STAMPS
+        const uint64_t occP__ = __ballot(st == PROBE), occE__ = __ballot(st == EXTEND);
+        if (t == 0) {   // lane occupancy of the matcher's blocks in this trip (wavefront 0)
+          const uint32_t nP = (uint32_t)__builtin_popcountll(occP__), nE = (uint32_t)__builtin_popcountll(occE__);
+          const uint32_t nF = (uint32_t)__builtin_popcountll(need);
+          stamp_acc[16] += nF != 0; stamp_acc[17] += nF; stamp_acc[18] += nP != 0; stamp_acc[19] += nP; stamp_acc[20] += nE != 0; stamp_acc[21] += nE;
+        }
+#endif
         bool fin = false;  // candidate kk finished with length ml
         if (st == PROBE) {
           q = qn;
@@ -738,14 +758,14 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           // a candidate the byte-4 filter rejects (37 % of them on text) is consumed on the spot and the next one takes
           // its place in this trip: the filter needs nothing but the two prefetched values
           // (classes with the filter array only: where byte 4 is a dependent window read the second test costs more than it saves)
-          if (!NOK && best >= 4 && kb != (pw1 & 0xFFu) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX) ) {
+          if (!NOK && rejects(kb) && kk < kmax && !(TCAP > (int)WMAX && p - q > WMAX) ) {
             kk++;
             q = qn; kb = kn;
             if (kk < kmax) { qn = S[i - kk - 1]; kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - kk - 1]; }
           }
           fin = true; ml = 0;
           if (TCAP > (int)WMAX && p - q > WMAX) kk = kmax;             // farther ones are farther still
-          else if (best >= 4 && kb != (pw1 & 0xFFu)) { }               // byte 4 differs: at most 4 <= best
+          else if (rejects(kb)) { }                                    // another 4-gram, or byte 4 differs: at most 4 <= best
           else {
             // random-address window reads only for candidates that can still win
             const uint32_t cprobe = ld32a(W, q + best - 3);
@@ -987,7 +1007,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
 #endif
   }
 #ifdef HMSE_DFL_STAMPS
-  if (t == 0) for (int i = 0; i < 16; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
+  if (t == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
 #endif
 }
 
@@ -1494,7 +1514,7 @@ extern "C" int hmse_debug_encode_stamps(unsigned long long* out8, int reset) {
 }
 extern "C" int hmse_debug_deflate_stamps(unsigned long long* out96, int reset) {
   if (hipMemcpyFromSymbol(out96, HIP_SYMBOL(dfl::g_dfl_stamps), sizeof(dfl::g_dfl_stamps)) != hipSuccess) return HMSE_EHIP;
-  if (reset) { unsigned long long z[96] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
+  if (reset) { unsigned long long z[144] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dfl::g_dfl_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
   return HMSE_OK;
 }
 #endif
