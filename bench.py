@@ -96,16 +96,41 @@ def _cpu_segment_oracle_deflate(args):
     return int(off[-1])
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: the scheduler affinity and the cgroup CPU quota count, not just os.cpu_count()
+    (a one-GPU box of the pool shows all 256 cores of its host but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
     """The Python zlib/hashlib + oracle CPU path on a bounded sample: all host cores, and one core.
     Runs BEFORE the process touches the GPU (it forks workers)."""
     import multiprocessing as mp
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     seg = 4 << 20
-    # every host core gets work: two 4 MiB segments per core (bounded at 2 GiB), ~3 s of one-core work each
-    nseg = sample_mib // 4 if sample_mib else min(2 * cores, 512)
+    # every usable host core gets work: eight 4 MiB segments per core (bounded at 2 GiB), ~1.3 s of one-core work each
+    nseg = sample_mib // 4 if sample_mib else min(8 * cores, 512)
     nseg = max(1, min(nseg, host.size // seg))
     segs = [(host[i * seg:(i + 1) * seg], {}) for i in range(nseg)]
     workers = min(cores, nseg)
@@ -118,7 +143,7 @@ def cpu_baseline(host: np.ndarray, sample_mib: int) -> dict:
         dt = time.time() - t0
         stored_orc = sum(pool.map(_cpu_segment_oracle_deflate, [(s[0], s[1], r[2], r[3], r[4]) for s, r in zip(segs, res)]))
     nbytes = nseg * seg
-    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": workers, "host_cores": cores, "kind": "port",
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": workers, "host_cores": os.cpu_count() or 1, "usable_cores": cores, "kind": "port",
             "one_core_GiB_per_s": seg / dt1 / 2**30,
             "sample": f"first {nseg} x 4 MiB segments of the same corpus ({nbytes >> 20} MiB), each segment its own dedupe/LSH scope: oracle "
                       f"FastCDC + hashlib.sha256 + dedupe + oracle MinHash/LSH + zlib level 9 (raw, zdict = LSH base, delta rule), one "

@@ -253,6 +253,54 @@ def test_l1_deflate_edges(orc, dev):
     assert want_kind[9] == 2 and want_kind[5] == 0
 
 
+def test_l1_deflate_dictionary_jobs_adversarial(orc, dev):
+    """Dictionary jobs of every size class under inputs that stress the round-3 paths (rule 2c hint pass, the wavefront's window
+    queue, rule 7's second pass): identical chunk and dictionary (every position hinted: the queue finds no work), unrelated
+    dictionary (nothing hinted: every position walks, the delta is refused and FULL comes from the second pass), one hot bucket
+    (a 4-byte period: thousands of candidates per position), runs that end inside the first 16 bytes, dictionaries longer than
+    the window, 32 KiB + 32 KiB (class B), tiny chunks with tiny dictionaries, edits at block boundaries."""
+    from hmse_amd import IngestConfig, ops
+    rng = np.random.Generator(np.random.PCG64(4242))
+    text = words_text(70000, seed=23)
+    def edit(a, k, seed):
+        r = np.random.default_rng(seed); v = a.copy(); v[r.integers(0, len(v), k)] = 35; return v
+    period = np.tile(np.frombuffer(b"abcd", np.uint8), 6000)
+    parts, base = [], []
+    def add(chunk, dict_=None):
+        if dict_ is not None:
+            parts.append(np.asarray(dict_, np.uint8)); base.append(-1)
+            parts.append(np.asarray(chunk, np.uint8)); base.append(len(parts) - 2)
+        else:
+            parts.append(np.asarray(chunk, np.uint8)); base.append(-1)
+    for L in (2048, 4500, 6100, 8000, 10700, 16000, 32768):                 # T = 2L: classes S .. B
+        a = text[100:100 + L]
+        add(a.copy(), a)                                                   # identical
+        add(edit(a, 3, L), a)                                              # near-duplicate
+        add(rng.integers(0, 256, L, dtype=np.uint8), a)                    # unrelated dictionary
+        v = a.copy(); v[63::64] ^= 1; add(v, a)                            # an edit in every 64-byte block: anchors fail or runs are short
+    add(period[:9000], period[:7000]); add(period[:20000], period[2:20002])   # one hot bucket, shifted diagonal
+    add(np.zeros(30000, np.uint8), np.zeros(32768, np.uint8))
+    add(text[:5], text[:7]); add(text[:3], text[:2]); add(text[:70], text[3:60])   # tiny
+    add(np.concatenate([text[:3000], text[:3000]]), edit(text[:3000], 2, 1))       # a repeat inside the chunk AND a dictionary (rule 2c takes the hint)
+    data = np.concatenate(parts)
+    cuts = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    base = np.array(base, np.int64)
+    for lvl_cfg in (IngestConfig(), IngestConfig(chain_depth=3), IngestConfig(delta_max_ratio_pct=20)):
+        want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, ocfg(orc, lvl_cfg), None, base)
+        out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), lvl_cfg, None, to_dev(base, dev))
+        assert np.array_equal(kind.cpu().numpy(), want_kind)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(out.cpu().numpy(), want_out)
+    k = want_kind[np.array(base) >= 0]
+    assert (k == 2).sum() >= 15 and (k == 0).sum() >= 7                   # both outcomes of rule 7 occur (incl. FULL via the second pass)
+    import zlib
+    o = out.cpu().numpy()
+    for j in range(len(parts)):                                            # every record inflates through stock zlib
+        st = o[int(want_off[j]):int(want_off[j + 1])].tobytes()
+        d = zlib.decompressobj(-15, zdict=parts[base[j]].tobytes()[-32768:]) if want_kind[j] == 2 else zlib.decompressobj(-15)
+        assert d.decompress(st) == parts[j].tobytes()
+
+
 def test_l1_deflate_near_incompressible_record_slots(orc, dev):
     """Streams whose size is within a byte of the stored size (L + 4 of L + 5), at 256 consecutive chunk lengths: the
     encode kernel copies its bit image out in whole 16-byte stores, which must not reach the neighbouring job record
