@@ -63,7 +63,7 @@ class DistStreamIngest:
 
     def __init__(self, cfg: IngestConfig, capacity_bytes: int, piece_bytes: int, device, world: int, rank: int,
                  max_chunks_global: int | None = None, max_chunks: int | None = None, stream_capacity: int | None = None,
-                 graph: bool = True, group=None, exchange=None):
+                 graph: bool = True, group=None, exchange=None, always_exchange: bool = False):
         if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
             raise ValueError("DistStreamIngest runs the full L1-L4 pipeline")
         if piece_bytes <= 0 or piece_bytes % cfg.seg_size:
@@ -108,13 +108,14 @@ class DistStreamIngest:
         self.graph = bool(graph)
         self._graphs: dict[int, list] = {}      # piece bytes -> [seg_off, graph A or None, graph B or None, uses]
         self._exchange = exchange
+        self._always_exchange = bool(always_exchange)    # world size 1 still runs the collective (hardware rehearsal of the graph / RCCL interleaving)
         self.n_batches = 0
 
     # ------------------------------------------------------------------ the exchange step
     def _all_gather(self, row: torch.Tensor) -> torch.Tensor:
         if self._exchange is not None:
             return self._exchange(row)
-        if self.world == 1:
+        if self.world == 1 and not self._always_exchange:
             return row
         return all_gather_rows(row, self.world, self.group, out=self._rows)
 

@@ -265,3 +265,34 @@ def test_two_processes_over_gloo_equal_the_lock_step_emulation(dev):
         for nm in NAMES + ("gidx",):
             assert np.array_equal(arrs[nm], want[rank][nm]), (rank, nm)
     assert got[0][2] == got[1][2] == sum(len(w["gidx"]) for w in want)
+
+
+def test_world_size_1_stream_with_the_rccl_all_gather_between_the_graph_replays(dev):
+    """What one GPU can show of the N-rank loop on RCCL itself: backend "nccl" at world size 1 with always_exchange — every
+    batch is replay(graph A) -> all_gather_into_tensor on RCCL's stream ordering -> replay(graph B) reading the gathered rows —
+    and the result is the single-rank stream's.  (Two ranks cannot share one device under RCCL; N > 1 is the gloo test above.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from hmse_amd import IngestConfig, ingest, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()[: 10 << 20]
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s = stream_dist.DistStreamIngest(cfg, data.size, 2 << 20, dev, 1, 0, graph=True, always_exchange=True)
+        for a in range(0, data.size, 2 << 20):
+            s.push(torch.from_numpy(data[a: a + (2 << 20)].copy()).pin_memory())
+        res = s.finish()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    e = s._graphs[2 << 20]
+    assert e[1] is not None and e[2] is not None and e[3] == 5
+    for name in NAMES:
+        assert torch.equal(getattr(res, name), getattr(whole, name)), name
