@@ -102,6 +102,20 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP path of the vector ALU (row shifts inside the 16-lane rows, then the two row
+// broadcasts of the GFX9 family): no LDS crossbar round trips (ds_bpermute, which is what __shfl_up compiles to)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
+
 template <int N>
 struct HuffScratchT {
   uint32_t key[N];         // compacted (freq << 9 | sym)
@@ -248,32 +262,29 @@ __device__ void huff_lengths_wave(const uint32_t* freq, uint32_t n, uint32_t lim
   wave_sync();
 }
 
-// canonical codes (bit-reversed for LSB-first packing); one wavefront.  cnt: >= 48 u32 of LDS scratch
-// (cnt[0..15] codes per length, cnt[16..31] first code of each length, advanced block by block).
+// canonical codes (bit-reversed for LSB-first packing); one wavefront.  cnt: >= 16 u32 of LDS scratch (codes per length).
+// A symbol's code = next[len] + (#earlier symbols with the same length)  (RFC 1951 3.2.2); the running next code of every length
+// is wave-uniform and stays in scalar registers: no LDS round trip between the blocks of 64 symbols.
 __device__ void huff_codes_wave(const uint8_t* lens, uint32_t n, uint16_t* codes, uint32_t* cnt) {
   const uint32_t lane = lane_id();
-  if (lane < 32) cnt[lane] = 0;
+  if (lane < 16) cnt[lane] = 0;
   wave_sync();
   for (uint32_t s = lane; s < n; s += 64) if (lens[s]) atomicAdd(&cnt[lens[s]], 1u);
   wave_sync();
-  if (lane >= 1 && lane <= 15) {  // next_code[b] = sum_{j<b} cnt[j] << (b-j)   (RFC 1951 3.2.2)
-    uint32_t code = 0;
-    for (uint32_t j = 1; j < lane; j++) code += cnt[j] << (lane - j);
-    cnt[16 + lane] = code;
-  }
-  wave_sync();
-  // a symbol's code = next[len] + (#earlier symbols with the same length)
+  uint32_t run[16];
+  uint32_t code = 0;
+  run[0] = 0;
+#pragma unroll
+  for (uint32_t b = 1; b <= 15; b++) { code = (code + (b > 1 ? uni32(cnt[b - 1]) : 0u)) << 1; run[b] = code; }
   for (uint32_t b0 = 0; b0 < n; b0 += 64) {
     const uint32_t s = b0 + lane;
     const uint32_t l = s < n ? lens[s] : 0u;
     uint32_t mycode = 0;
+#pragma unroll
     for (uint32_t b = 1; b <= 15; b++) {
       const uint64_t mask = __ballot(l == b);
-      if (mask == 0) continue;
-      if (l == b) mycode = cnt[16 + b] + (uint32_t)__builtin_popcountll(mask & lanemask_lt());
-      wave_sync();
-      if (lane == 0) cnt[16 + b] += (uint32_t)__builtin_popcountll(mask);
-      wave_sync();
+      if (l == b) mycode = run[b] + (uint32_t)__builtin_popcountll(mask & lanemask_lt());
+      run[b] += (uint32_t)__builtin_popcountll(mask);
     }
     if (s < n) codes[s] = l ? (uint16_t)(__builtin_bitreverse32(mycode) >> (32 - l)) : (uint16_t)0;
   }
@@ -329,10 +340,8 @@ __device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint3
       else { const uint32_t r1 = R - 1; full = r1 / 6; rem = r1 % 6; cnt = 1 + full + (rem >= 3 ? 1u : rem); }
     }
     // exclusive scan of cnt over the wave
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
-    const uint32_t tot = __shfl(inc, 63, 64);
+    const uint32_t inc = wave_incl_scan(cnt);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     uint32_t at = base + inc - cnt;
     if (is_start) {
       if (v == 0) {
@@ -1023,7 +1032,9 @@ struct EncLayout {
   static constexpr int HS_SZ = align16((int)(sizeof(HuffL) + sizeof(HuffD)));
   static constexpr int OUT_OFF = HS_OFF;                // the bit image reuses the Huffman scratch (dead once the codes exist)
   static constexpr int OUT_SZ = align16(LCAP + 80);
-  static constexpr int TOTAL = OUT_OFF + (OUT_SZ > HS_SZ ? OUT_SZ : HS_SZ);
+  static constexpr int TT_OFF = OUT_OFF + (OUT_SZ > HS_SZ ? OUT_SZ : HS_SZ);   // u32 TT[512]: a token's first part, ready to emit
+  static constexpr int TT_SZ = 512 * 4;
+  static constexpr int TOTAL = TT_OFF + TT_SZ;
 };
 
 template <int NT, int LMIN, int LCAP>
@@ -1034,6 +1045,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   HuffL* const hsL = (HuffL*)(smem + EL::HS_OFF);
   HuffD* const hsD = (HuffD*)(smem + EL::HS_OFF + sizeof(HuffL));
   uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
+  uint32_t* const TT = (uint32_t*)(smem + EL::TT_OFF);
   const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
@@ -1076,7 +1088,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     uint32_t fb = 0, xb = 0;
     for (uint32_t s = lane; s < 286; s += 64) { fb += sm.lf[s] * fixed_len(s); if (s >= 257) xb += sm.lf[s] * len_extra_bits(s); }
     if (lane < 30) { fb += sm.df[lane] * 5u; xb += sm.df[lane] * dist_extra_bits(lane); }
-    for (int d = 32; d > 0; d >>= 1) { fb += __shfl_down(fb, d, 64); xb += __shfl_down(xb, d, 64); }
+    fb = wave_sum(fb); xb = wave_sum(xb);
     if (lane == 0) { sm.fixed_bits = fb + xb + 3; sm.extra_bits = xb; }
   }
   __syncthreads();
@@ -1104,14 +1116,14 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     if (ncl < 4) ncl = 4;
     uint32_t cb = 0;
     for (uint32_t i = lane; i < e2; i += 64) cb += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
-    for (int d = 32; d > 0; d >>= 1) cb += __shfl_down(cb, d, 64);
+    cb = wave_sum(cb);
     if (lane == 0) { sm.ncl = ncl; sm.cl_bits = cb; }
   }
   if (wave == 1) {
     uint32_t db = 0;
     for (uint32_t s = lane; s < 286; s += 64) db += sm.lf[s] * sm.ll[s];
     if (lane < 30) db += sm.df[lane] * sm.dl[lane];
-    for (int d = 32; d > 0; d >>= 1) db += __shfl_down(db, d, 64);
+    db = wave_sum(db);
     if (lane == 0) sm.data_bits = db;
   }
   __syncthreads();
@@ -1148,6 +1160,20 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
   __syncthreads();
   for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;  // (the image shares LDS with the scratch used above)
+  // TT[low half of a token] = the bits of its first part (literal code | length code + extra bits: <= 20 bits) | bit count << 24;
+  // df[distance code] = code | length << 16 (the histogram is dead).  The emit loops then do one table read per part.
+  for (uint32_t ts = t; ts < 512u; ts += NT) {
+    uint32_t e;
+    if (ts < 256u) e = (uint32_t)sm.lc[ts] | ((uint32_t)sm.ll[ts] << 24);
+    else {
+      uint32_t code, eb, ev;
+      len_sym(ts - 253u, code, eb, ev);
+      const uint32_t l1 = sm.ll[code];
+      e = (uint32_t)sm.lc[code] | (ev << l1) | ((l1 + eb) << 24);
+    }
+    TT[ts] = e;
+  }
+  if (t < 32) sm.df[t] = (uint32_t)sm.dc[t] | ((uint32_t)sm.dl[t] << 16);
   __syncthreads();
   ESTAMP(e_acc3);
   // ---- phase 11: emit ----------------------------------------------------------------------------------------
@@ -1162,9 +1188,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
       const uint32_t i0 = lane * per, i1 = (i0 + per) < nr ? (i0 + per) : nr;
       uint32_t bits = 0;
       for (uint32_t i = i0; i < i1; i++) bits += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
-      uint32_t inc = bits;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
+      const uint32_t inc = wave_incl_scan(bits);
       uint32_t off = 17 + 3 * sm.ncl + inc - bits;
       for (uint32_t i = i0; i < i1; i++) {
         const uint32_t s = sm.rle_sym[i], l = sm.cl[s], eb = sm.rle_eb[i];
@@ -1180,17 +1204,24 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   const uint32_t tw0 = wave * wq, tw1 = (tw0 + wq) < ntok ? (tw0 + wq) : ntok;
   auto tokbits = [&](uint32_t tk) -> uint32_t {
     const uint32_t ts = tk & 0xFFFFu;
+    uint32_t b = TT[ts] >> 24;
     if (ts >= 256u) {
-      uint32_t code, eb, ev, dcode, deb, dev;
-      len_sym(ts - 253u, code, eb, ev);
+      uint32_t dcode, deb, dev;
       dist_sym(tk >> 16, dcode, deb, dev);
-      return sm.ll[code] + eb + sm.dl[dcode] + deb;
+      b += (sm.df[dcode] >> 16) + deb;
     }
-    return sm.ll[ts];
+    return b;
   };
   uint32_t mybits = 0;
-  for (uint32_t i = tw0 + lane; i < tw1; i += 64) mybits += tokbits(tok[i]);
-  for (int d = 32; d > 0; d >>= 1) mybits += __shfl_down(mybits, d, 64);
+  {  // four independent token loads in flight per lane (the records left the caches long ago: one HBM round trip per load)
+    uint32_t i = tw0 + lane;
+    for (; i + 192u < tw1; i += 256u) {
+      const uint32_t t0 = tok[i], t1 = tok[i + 64u], t2 = tok[i + 128u], t3 = tok[i + 192u];
+      mybits += tokbits(t0) + tokbits(t1) + tokbits(t2) + tokbits(t3);
+    }
+    for (; i < tw1; i += 64u) mybits += tokbits(tok[i]);
+  }
+  mybits = wave_sum(mybits);
   if (lane == 0) sm.red[wave] = mybits;
   __syncthreads();
   uint32_t total = 0, wstart = sm.hdr_bits;
@@ -1198,26 +1229,37 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   for (uint32_t w = 0; w < NWV; w++) { const uint32_t c = sm.red[w]; total += c; if (w < wave) wstart += c; }
   {
     uint32_t running = wstart;
+    uint32_t tk_n1 = (tw0 + lane) < tw1 ? tok[tw0 + lane] : 0u, tk_n2 = (tw0 + lane + 64u) < tw1 ? tok[tw0 + lane + 64u] : 0u;
     for (uint32_t i0 = tw0; i0 < tw1; i0 += 64) {
       const uint32_t i = i0 + lane;
-      const uint32_t tk = i < tw1 ? tok[i] : 0u;
-      const uint32_t b = i < tw1 ? tokbits(tk) : 0u;
-      uint32_t inc = b;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t2; }
-      uint32_t off = running + inc - b;
-      running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      const uint32_t tk = tk_n1;      // loaded two steps ahead
+      tk_n1 = tk_n2;
+      tk_n2 = (i + 128u) < tw1 ? tok[i + 128u] : 0u;
+      // the token's bits: literal / length part (v1, nb1 <= 20 bits) from the table, distance part (v2, nb2 <= 28 bits)
+      uint32_t v1 = 0, nb1 = 0, v2 = 0, nb2 = 0;
       if (i < tw1) {
         const uint32_t ts = tk & 0xFFFFu;
+        const uint32_t e = TT[ts];
+        v1 = e & 0xFFFFFFu; nb1 = e >> 24;
         if (ts >= 256u) {
-          uint32_t code, eb, ev, dcode, deb, dev;
-          len_sym(ts - 253u, code, eb, ev);
+          uint32_t dcode, deb, dev;
           dist_sym(tk >> 16, dcode, deb, dev);
-          const uint32_t l1 = sm.ll[code], l2 = sm.dl[dcode];
-          put_bits(out, off, (uint32_t)sm.lc[code] | (ev << l1), l1 + eb); off += l1 + eb;
-          put_bits(out, off, (uint32_t)sm.dc[dcode] | (dev << l2), l2 + deb);
-        } else {
-          put_bits(out, off, sm.lc[ts], sm.ll[ts]);
+          const uint32_t d = sm.df[dcode], l2 = d >> 16;
+          v2 = (d & 0xFFFFu) | (dev << l2); nb2 = l2 + deb;
+        }
+      }
+      const uint32_t b = nb1 + nb2;
+      const uint32_t inc = wave_incl_scan(b);
+      const uint32_t off = running + inc - b;
+      running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      if (b) {   // one put of up to 48 bits: at most three dwords of the image
+        const uint64_t v = (uint64_t)v1 | ((uint64_t)v2 << nb1);
+        const uint32_t w = off >> 5, sh = off & 31u;
+        atomicOr(&out[w], (uint32_t)v << sh);
+        if (sh + b > 32u) {
+          const uint64_t rest = (v >> 1) >> (31u - sh);
+          atomicOr(&out[w + 1], (uint32_t)rest);
+          if (sh + b > 64u) atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
         }
       }
     }
