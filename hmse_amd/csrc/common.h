@@ -53,16 +53,32 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_rotateleft32(x, r); }
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int r) { return __builtin_rotateright32(x, r); }
 
+// inclusive prefix sum over the 64 lanes on the DPP path of the vector ALU (row shifts inside the 16-lane rows, then the two row
+// broadcasts of the GFX9 family): no LDS crossbar round trips (ds_bpermute, which is what __shfl_up compiles to)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+
+// the maximum over the 64 lanes, in every lane (same DPP ladder; 0 is the identity)
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#define HMSE_DPP_MAX(ctrl, rows) { const uint32_t o__ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false); v = v > o__ ? v : o__; }
+  HMSE_DPP_MAX(0x111, 0xF) HMSE_DPP_MAX(0x112, 0xF) HMSE_DPP_MAX(0x114, 0xF) HMSE_DPP_MAX(0x118, 0xF) HMSE_DPP_MAX(0x142, 0xA) HMSE_DPP_MAX(0x143, 0xC)
+#undef HMSE_DPP_MAX
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
+
 // workgroup exclusive scan of one u32 per thread (NT threads, NT <= 1024). `red` = LDS u32[NT/64 + 1].
 template <int NT>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* red, uint32_t* total) {
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= (uint32_t)d) inc += t;
-  }
+  const uint32_t inc = wave_incl_scan(v);
   if (lane == 63) red[wave] = inc;
   __syncthreads();
   uint32_t wbase = 0, tot = 0;

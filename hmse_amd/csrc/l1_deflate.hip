@@ -102,20 +102,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// inclusive prefix sum over the 64 lanes on the DPP path of the vector ALU (row shifts inside the 16-lane rows, then the two row
-// broadcasts of the GFX9 family): no LDS crossbar round trips (ds_bpermute, which is what __shfl_up compiles to)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
-  return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
-
 template <int N>
 struct HuffScratchT {
   uint32_t key[N];         // compacted (freq << 9 | sym)
@@ -577,10 +563,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             }
           }
           uint32_t key = (ml << 8) | lane;   // longest, then nearest (highest lane)
-#pragma unroll
-          for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)key, sft, 64); key = key > o ? key : o; }
+          key = wave_max(key);
           if ((key >> 8) >= 32u) {
-            const uint32_t d = pa - (uint32_t)__shfl((int)q, (int)(key & 63u), 64);
+            const uint32_t d = pa - (uint32_t)__builtin_amdgcn_readlane((int)q, (int)(key & 63u));
             // 512 bytes along the diagonal, 8 per lane
             const uint32_t off = 8u * lane;
             uint32_t n = 8;
@@ -592,7 +577,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             } else n = 0;
             const uint64_t mm = __ballot(n < 8u);
             uint32_t run = 512;
-            if (mm) { const uint32_t fl = (uint32_t)__builtin_ctzll(mm); run = 8u * fl + (uint32_t)__shfl((int)n, (int)fl, 64); }
+            if (mm) { const uint32_t fl = (uint32_t)__builtin_ctzll(mm); run = 8u * fl + (uint32_t)__builtin_amdgcn_readlane((int)n, (int)fl); }
             if (run > T - pa) run = T - pa;
             word = d | (run << 16);
           }
@@ -743,7 +728,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           const uint32_t leader = (uint32_t)__builtin_ctzll(need);
           uint32_t base = 0;
           if (lane == leader) base = atomicAdd(&sm.qhead, (uint32_t)__builtin_popcountll(need));
-          base = (uint32_t)__shfl((int)base, (int)leader, 64);
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);   // leader is wave-uniform: v_readlane, no LDS crossbar trip
           if (st == FETCH) {
             const uint32_t ii = base + mbcnt64(need);
             if (ii >= nh) st = DONE;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void l3_sha256_kernel(const uint8_t* __restric
       const uint32_t leader = (uint32_t)__builtin_ctzll(need);
       unsigned long long base = 0;
       if (lane == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(need));
-      base = __shfl(base, leader, 64);
+      base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)leader) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
       if (phase == 3) {
         const uint64_t slot = base + (uint64_t)__builtin_popcountll(need & lanemask_lt());
         if (slot < n_chunks) {

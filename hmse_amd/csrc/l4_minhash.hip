@@ -285,8 +285,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       uint32_t lo = 0xFFFFFFFFu;
       for (uint32_t i = lane; i < wr; i += 64) lo = min(lo, murmur_tail<V>(q[i], sr));
       if (w == 0 && s_flag) lo = min(lo, murmur_tail<V>(MH_EMPTY, sr));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+      lo = ~wave_max(~lo);   // minimum over the wavefront on the DPP path
       if (lane == 0) atomicMin(&s_pass[sd], lo);
     }
     __syncthreads();
