@@ -352,7 +352,7 @@ __device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint3
 // diagnostic build only: per-phase shader-clock totals of thread 0, summed over jobs and workgroups
 __device__ unsigned long long g_dfl_stamps[6][24];   // [size group + 3 * dictionary jobs][phase]
 __device__ unsigned long long g_enc_stamps[8];   // encode kernel: clocks of thread 0 per phase (0 load, 1 trees, 2 rle+cl+decide, 3 codes, 4 emit, 5 copy-out), [7] records
-#define STAMP(i) do { if (t == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); stamp_acc[i] += now__ - stamp_last; stamp_last = now__; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -406,31 +406,36 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
   uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
   uint16_t* const jump = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->jumpA;
   uint8_t* const K = LDSM ? (uint8_t*)(smem + LY::K_OFF) : sc->K;
-  const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
   unsigned long long stamp_acc[24] = {0}, stamp_last = clock64();
 #endif
 
   for (;;) {
+    // (the thread index re-read behind a compiler barrier per job: nothing derived from it is hoisted out of this persistent
+    // loop and kept in registers across the matcher — see the encode kernel)
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const uint32_t lane = t & 63u, wave = t >> 6;
     __syncthreads();
     if (t == 0) sm.job = atomicAdd(a.counter, 1u);
     __syncthreads();
-    const uint32_t ji = sm.job;
+    const uint32_t ji = uni32(sm.job);   // wave-uniform, and said so: the job's metadata chain (list entry, chunk id, cuts, record offset) becomes scalar loads,
+                                         // lengths and loop bounds live in SGPRs
     if (ji >= n_jobs) break;
     STAMP(10);
-    const uint32_t job = a.jobs[ji];
+    const uint32_t job = uni32(a.jobs[ji]);
     const uint64_t k = job >> 1;
     constexpr uint32_t variant = DICT ? 1u : 0u;  // (== job & 1: the lists are split by variant)
-    const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
-    const uint64_t cstart = a.cuts[c];
-    const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
+    const uint64_t c = a.chunk_ids ? uni64(a.chunk_ids[k]) : k;
+    const uint64_t cstart = uni64(a.cuts[c]);
+    const uint32_t L = uni32((uint32_t)(a.cuts[c + 1] - cstart));
     uint32_t Dl = 0; uint64_t dstart = 0;
     if (variant == 1) {
-      const int64_t bsel = a.base[k];
-      const uint64_t bc = (a.chunk_ids && !a.base_is_chunk) ? a.chunk_ids[bsel] : (uint64_t)bsel;
-      dstart = a.cuts[bc];
-      uint64_t dl64 = a.cuts[bc + 1] - dstart;
+      const int64_t bsel = (int64_t)uni64((uint64_t)a.base[k]);
+      const uint64_t bc = (a.chunk_ids && !a.base_is_chunk) ? uni64(a.chunk_ids[bsel]) : (uint64_t)bsel;
+      dstart = uni64(a.cuts[bc]);
+      uint64_t dl64 = uni64(a.cuts[bc + 1]) - dstart;
       if (dl64 > WMAX) { dstart += dl64 - WMAX; dl64 = WMAX; }
       Dl = (uint32_t)dl64;
     }
@@ -438,12 +443,13 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     const uint32_t T = Dl + L;
     // job record: histograms and the token list go to the encode kernel through it.  Classes S2/SG/B keep the match
     // distances (S2) or lengths and distances (SG, B) in a per-workgroup global array while matching.
-    uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
+    const uint64_t rec_at = uni64(a.rec_off[k]);
+    uint8_t* const rec = a.recs + rec_at + (variant ? rec_size(L) : 0u);
     uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
     uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
     // A dictionary job yields the chunk's DELTA record only (round 3, rule 7 of the oracle): the FULL record of a chunk with a
     // base is produced by a plain job in a second pass, and only when the delta turns out larger than a fifth of the chunk.
-    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || a.rec_off[k] + (variant + 1ull) * rec_size(L) > a.rec_cap) {
+    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || rec_at + (variant + 1ull) * rec_size(L) > a.rec_cap) {
       if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
       continue;
     }
@@ -505,6 +511,8 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // step's increments, complete at the first barrier) sits in front of the second one, so that barrier also separates
       // it from the next step's increments; the in-place rewrite of this step's slots [before, after) then runs beside the
       // next step's scatter into slots >= after.
+      // (Measured, round 3: two or four positions per thread and step — half / a quarter of the barriers — are SLOWER, +4.5 % / +14 %
+      // on the match kernels: the quadratic rank runs over the step's duplicates, and a step of 2048 positions has four times the pairs.)
       // (filter byte of a position: low nibble of its byte 4 | four more bits of its hash product, see the matcher's `rejects`)
       uint32_t q = t, h = 0, before = 0, hx = 0;
       bool act = q < nh;
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         uint32_t r = 0;
         if (act) {
           const uint32_t after = cur_get(cur, h);
-          for (uint32_t jj = before; jj < after; jj++) r += S[jj] < q;
+          for (uint32_t jj = before; jj < after; jj++) r += S[jj] < q;   // (measured: four slots per round trip is slower, +3 % — the usual trip count is one)
         }
         const uint32_t qn = q0 + NT + t;
         const bool actn = qn < nh;
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
 #endif
   }
 #ifdef HMSE_DFL_STAMPS
-  if (t == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
+  if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
 #endif
 }
 
@@ -1031,32 +1039,37 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   HuffD* const hsD = (HuffD*)(smem + EL::HS_OFF + sizeof(HuffL));
   uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
   uint32_t* const TT = (uint32_t*)(smem + EL::TT_OFF);
-  const uint32_t t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
   unsigned long long e_acc0 = 0, e_acc1 = 0, e_acc2 = 0, e_acc3 = 0, e_acc4 = 0, e_acc5 = 0, e_n = 0, e_last = clock64();
-#define ESTAMP(v) do { if (t == 0) { const unsigned long long now__ = clock64(); v += now__ - e_last; e_last = now__; } } while (0)
+#define ESTAMP(v) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); v += now__ - e_last; e_last = now__; } } while (0)
 #else
 #define ESTAMP(v) do { } while (0)
 #endif
   for (;;) {
+  // The thread index is re-read behind a compiler barrier in every round: otherwise everything derived from it (dozens of
+  // `t < 288`-style masks, LDS addresses) is hoisted out of this persistent loop and held in registers across all phases —
+  // 38 VGPRs spilled to scratch under the 64-register cap that eight workgroups per CU need (tools/kernel_regs.py)
+  uint32_t t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const uint32_t lane = t & 63u, wave = t >> 6;
   __syncthreads();
   if (t == 0) sm.job = atomicAdd(a.counter, 1u);
   __syncthreads();
-  const uint32_t ji = sm.job;
+  const uint32_t ji = uni32(sm.job);   // (scalar metadata chain, as in the match kernel)
   if (ji >= n_jobs) break;
-  const uint32_t job = a.jobs[ji];
+  const uint32_t job = uni32(a.jobs[ji]);
   const uint64_t k = job >> 1;
   const uint32_t variant = job & 1u;
-  const uint64_t c = a.chunk_ids ? a.chunk_ids[k] : k;
-  const uint64_t cstart = a.cuts[c];
-  const uint32_t L = (uint32_t)(a.cuts[c + 1] - cstart);
+  const uint64_t c = a.chunk_ids ? uni64(a.chunk_ids[k]) : k;
+  const uint64_t cstart = uni64(a.cuts[c]);
+  const uint32_t L = uni32((uint32_t)(a.cuts[c + 1] - cstart));
   if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) continue;  // (lists are split by length: cannot happen)
   uint32_t* len_out = variant ? a.len_delta : a.len_full;
-  if (len_out[k] == 0xFFFFFFFFu) continue;                  // the match kernel could not take this job
-  uint8_t* const rec = a.recs + a.rec_off[k] + (variant ? rec_size(L) : 0u);
+  if (uni32(len_out[k]) == 0xFFFFFFFFu) continue;           // the match kernel could not take this job
+  uint8_t* const rec = a.recs + uni64(a.rec_off[k]) + (variant ? rec_size(L) : 0u);
   const uint32_t* const r_hist = (const uint32_t*)rec;
-  const uint32_t ntok = *(const uint32_t*)(rec + rec_ntok_off());
+  const uint32_t ntok = uni32(*(const uint32_t*)(rec + rec_ntok_off()));
   const uint32_t* const tok = (const uint32_t*)(rec + rec_tok_off());
   if (a.prof_ctr && t == 0) atomicAdd(&a.prof_ctr[a.prof_slot], (unsigned long long)ntok);
   uint8_t* const slot = rec + rec_slot_off(L);
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
 #endif
   }
 #ifdef HMSE_DFL_STAMPS
-  if (t == 0) {
+  if (threadIdx.x == 0) {
     atomicAdd(&g_enc_stamps[0], e_acc0); atomicAdd(&g_enc_stamps[1], e_acc1); atomicAdd(&g_enc_stamps[2], e_acc2); atomicAdd(&g_enc_stamps[3], e_acc3);
     atomicAdd(&g_enc_stamps[4], e_acc4); atomicAdd(&g_enc_stamps[5], e_acc5); atomicAdd(&g_enc_stamps[7], e_n);
   }
