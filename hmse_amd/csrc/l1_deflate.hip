@@ -357,23 +357,29 @@ __device__ unsigned long long g_enc_stamps[8];   // encode kernel: clocks of thr
 #define STAMP(i) do { } while (0)
 #endif
 
-// Per-job record in the workspace (written by the match kernel, read by the encode kernel):
-//   [lf u32[288]][df u32[32]][ntok u32 ...] | tok u32[L] | stream slot (L+5, the output)
+// Per-chunk record in the workspace (written by the match kernel, read by the encode kernel):
+//   [lf u32[288]][df u32[32]][ntok u32 ...] | tok u32[L] | chunks with a dictionary only: DELTA stream slot (L + 5, + 16 slack)
 // Tokens in parse order, one dword each: low half < 256 = literal byte; low half >= 256 = match of length
 // (low-253) at distance (high half).
+// ONE record per chunk (round 3; two per chunk with a dictionary and a separate slot before: 6.25 -> 4.25 x the stored bytes on
+// the headline corpus).  The dictionary job and — if the delta is no quick accept — the plain job of the same chunk use the same
+// histogram and token area one after the other (the launches are ordered: dictionary jobs, their encodes, then the plain jobs).
+// The FULL stream is written OVER the token list once the encode kernel has turned all of it into its LDS bit image (the
+// stream never exceeds L + 5 <= 4 * L bytes); the DELTA stream has its own slot behind the tokens, where it survives the plain job.
 __host__ __device__ __forceinline__ uint32_t rec_ntok_off() { return 1280u; }
 __host__ __device__ __forceinline__ uint32_t rec_tok_off() { return 1296u; }
-// The slot starts 16-byte aligned and carries 16 bytes beyond the largest stream (L + 5): the encode kernel copies its bit
-// image out in whole 16-byte stores, which must stay inside this record (the neighbour's histogram follows).
-__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L) { return 1296u + 4u * ((L + 3u) & ~3u); }
-__host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L) { return (rec_slot_off(L) + L + 5u + 16u + 255u) & ~255u; }
+__host__ __device__ __forceinline__ uint32_t rec_body(uint32_t L) { return 1296u + 4u * ((L + 3u) & ~3u); }   // histograms + tokens; 16-byte aligned
+// stream slots start 16-byte aligned: the encode kernel copies its bit image out in whole 16-byte stores, which stay inside the
+// token area (round_up_16(L + 5) <= 4 * round_up_4(L)) or the DELTA slot (16 bytes of slack)
+__host__ __device__ __forceinline__ uint32_t rec_slot_off(uint32_t L, uint32_t variant) { return variant ? rec_body(L) : rec_tok_off(); }
+__host__ __device__ __forceinline__ uint32_t rec_size(uint32_t L, bool has_dict) { return (rec_body(L) + (has_dict ? L + 5u + 16u : 0u) + 255u) & ~255u; }
 
 struct Args {
   const uint8_t* data; uint64_t n;
   const uint64_t* cuts; const uint64_t* chunk_ids; const int64_t* base; uint64_t n_sel;
   uint32_t depth;
   uint32_t base_is_chunk;    // base[] holds chunk indices (into cuts) instead of indices into the selection
-  const uint64_t* rec_off;   // [n_sel] byte offset of chunk k's record pair (FULL, then DELTA at + rec_size(L))
+  const uint64_t* rec_off;   // [n_sel] byte offset of chunk k's record
   uint8_t* recs;
   uint64_t rec_cap; uint32_t* status;
   uint32_t* len_full; uint32_t* len_delta;
@@ -444,12 +450,12 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     // job record: histograms and the token list go to the encode kernel through it.  Classes S2/SG/B keep the match
     // distances (S2) or lengths and distances (SG, B) in a per-workgroup global array while matching.
     const uint64_t rec_at = uni64(a.rec_off[k]);
-    uint8_t* const rec = a.recs + rec_at + (variant ? rec_size(L) : 0u);
+    uint8_t* const rec = a.recs + rec_at;
     uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
     uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
     // A dictionary job yields the chunk's DELTA record only (round 3, rule 7 of the oracle): the FULL record of a chunk with a
     // base is produced by a plain job in a second pass, and only when the delta turns out larger than a fifth of the chunk.
-    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || rec_at + (variant + 1ull) * rec_size(L) > a.rec_cap) {
+    if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || rec_at + (uint64_t)rec_size(L, variant != 0) > a.rec_cap) {
       if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
       continue;
     }
@@ -1071,12 +1077,12 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) continue;  // (lists are split by length: cannot happen)
   uint32_t* len_out = variant ? a.len_delta : a.len_full;
   if (uni32(len_out[k]) == 0xFFFFFFFFu) continue;           // the match kernel could not take this job
-  uint8_t* const rec = a.recs + uni64(a.rec_off[k]) + (variant ? rec_size(L) : 0u);
+  uint8_t* const rec = a.recs + uni64(a.rec_off[k]);
   const uint32_t* const r_hist = (const uint32_t*)rec;
   const uint32_t ntok = uni32(*(const uint32_t*)(rec + rec_ntok_off()));
   const uint32_t* const tok = (const uint32_t*)(rec + rec_tok_off());
   if (a.prof_ctr && t == 0) atomicAdd(&a.prof_ctr[a.prof_slot], (unsigned long long)ntok);
-  uint8_t* const slot = rec + rec_slot_off(L);
+  uint8_t* const slot = rec + rec_slot_off(L, variant);
   const uint8_t* const lit = a.data + cstart;
   for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = r_hist[i];
   if (t < 32) sm.df[t] = r_hist[288 + t];
@@ -1271,7 +1277,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   __syncthreads();
   ESTAMP(e_acc4);
   const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
-  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned and has 16 bytes of slack (rec_size)
+  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned; whole 16-byte stores stay inside it (rec_slot_off)
     const uint4 v = *(const uint4*)((const uint8_t*)out + i);
     *(uint4*)(slot + i) = v;
   }
@@ -1376,7 +1382,7 @@ __global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ 
   list_append(redo && L <= 32768, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
 }
 
-// record sizes: FULL (+ DELTA when a base exists)
+// record sizes (one record per chunk; a chunk with a dictionary has the DELTA stream's slot behind its tokens)
 __global__ __launch_bounds__(256) void rec_size_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel,
                                                         uint64_t* __restrict__ sizes, const uint64_t* __restrict__ n_dev) {
@@ -1385,8 +1391,7 @@ __global__ __launch_bounds__(256) void rec_size_kernel(const uint64_t* __restric
   if (k >= n_sel) return;
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
   const uint64_t len = cuts[c + 1] - cuts[c];
-  const uint64_t s = len <= 32768 ? rec_size((uint32_t)len) : 0u;
-  sizes[k] = (base && base[k] >= 0) ? 2 * s : s;
+  sizes[k] = len <= 32768 ? rec_size((uint32_t)len, base && base[k] >= 0) : 0u;
 }
 
 // kind decision (rule 7 of the oracle; README.md:1328, 2175) and final lengths
@@ -1432,7 +1437,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint64_t* __restrict_
   const uint64_t c = chunk_ids ? chunk_ids[k] : k;
   const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
   if (len > 32768u) return;
-  const uint8_t* src = recs + rec_off[k] + ((kind && kind[k] == HMSE_KIND_DELTA) ? rec_size(len) : 0u) + rec_slot_off(len);
+  const uint8_t* src = recs + rec_off[k] + rec_slot_off(len, (kind && kind[k] == HMSE_KIND_DELTA) ? 1u : 0u);
   const uint64_t o0 = out_off[k], o1 = out_off[k + 1];
   if (obase + o1 > out_cap) { if (threadIdx.x == 0) atomicOr(status, 1u); return; }
   const uint32_t nb = (uint32_t)(o1 - o0);
@@ -1563,9 +1568,10 @@ extern "C" int hmse_debug_deflate_stamps(unsigned long long* out96, int reset) {
 }
 #endif
 
-extern "C" uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len) { return chunk_len <= 32768u ? dfl::rec_size(chunk_len) : 0u; }
+extern "C" uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len) { return chunk_len <= 32768u ? dfl::rec_size(chunk_len, false) : 0u; }
+extern "C" uint64_t hmse_l1_deflate_record_bytes_dict(uint32_t chunk_len) { return chunk_len <= 32768u ? dfl::rec_size(chunk_len, true) : 0u; }
 
-// fixed part only; the caller adds the slot area: sum over chunks of align16(len+5) * (1 + has_base)
+// fixed part only; the caller adds the record area: sum over chunks of hmse_l1_deflate_record_bytes[_dict](len)
 size_t hmse_l1_deflate_workspace_bytes_impl(uint64_t n_sel, const hmse_cfg*) { return dfl::carve(nullptr, n_sel).fixed_bytes; }
 
 static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, const uint64_t* chunk_ids,
@@ -1610,7 +1616,7 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   Ws w = carve(ws, n_sel);
   if (!ws || ws_bytes < w.fixed_bytes) return HMSE_ENOSPC;
   // record area = whatever follows the fixed part; a job whose record does not fit sets status bit 1
-  // (needed: sum over selected chunks of rec_size(len) ~ 5*len + 1.6 KiB, twice where a base exists)
+  // (needed: sum over selected chunks of rec_size(len, has a base) ~ 4*len + 1.4 KiB, + len + 21 where a base exists)
   const uint64_t avail = ws_bytes - w.fixed_bytes;
   HMSE_FILL(w.counters, 0, N_CTR * sizeof(uint32_t), stream);
   HMSE_FILL(w.len_full, 0, n_sel * sizeof(uint32_t), stream);

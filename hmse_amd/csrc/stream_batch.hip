@@ -182,8 +182,8 @@ static sb::Ws sb_carve(void* ws, uint64_t cap_bytes, const hmse_cfg* cfg) {
   r.sha_ws = w.take<uint8_t>(r.sha_bytes);
   r.mh_bytes = hmse_l4_minhash_workspace_bytes_impl(cap);
   r.mh_ws = w.take<uint8_t>(r.mh_bytes);
-  // DEFLATE: fixed part + the record area for the worst case (every chunk stored, every one with a dictionary)
-  r.dfl_bytes = hmse_l1_deflate_workspace_bytes_impl(cap, cfg) + 2 * (5 * cap_bytes + 1600 * cap) + 4096;
+  // DEFLATE: fixed part + the record area for the worst case (every chunk with a dictionary: 5 * len + 1317 + padding to 256)
+  r.dfl_bytes = hmse_l1_deflate_workspace_bytes_impl(cap, cfg) + (5 * cap_bytes + 1600 * cap) + 4096;
   r.dfl_ws = w.take<uint8_t>(r.dfl_bytes);
   r.total = w.off;
   return r;

@@ -188,9 +188,13 @@ def l4_lsh(sig: torch.Tensor, cfg: IngestConfig):
     return keys, base
 
 
-def record_bytes(lens: torch.Tensor) -> torch.Tensor:
-    """hmse_l1_deflate_record_bytes() for a tensor of chunk lengths (0 above 32768: such a chunk is never encoded)."""
-    return torch.where(lens <= 32768, (1296 + 4 * ((lens + 3) & ~3) + lens + 5 + 16 + 255) & ~255, torch.zeros_like(lens))
+def record_bytes(lens: torch.Tensor, has_dict=None) -> torch.Tensor:
+    """hmse_l1_deflate_record_bytes() — where `has_dict` (bool tensor) is set: hmse_l1_deflate_record_bytes_dict() — for a
+    tensor of chunk lengths (0 above 32768: such a chunk is never encoded)."""
+    body = 1296 + 4 * ((lens + 3) & ~3)
+    if has_dict is not None:
+        body = body + torch.where(has_dict, lens + 21, torch.zeros_like(lens))
+    return torch.where(lens <= 32768, (body + 255) & ~255, torch.zeros_like(lens))
 
 
 DEFLATE_WS_LIMIT = 64 << 30   # upper bound of the per-job records one hmse_l1_deflate call may hold (l1_deflate splits a larger selection)
@@ -210,8 +214,8 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     """Per-chunk raw DEFLATE with the base chunk as dictionary (`base`: index into the selection, or — with
     base_is_chunk_id — a chunk index into `cuts`, e.g. a chunk stored by an earlier batch of a stream).
 
-    The C-ABI call keeps one record per job (histograms, token list sized for the all-literal worst case, stream slot:
-    ~5.2 x the chunk, twice for a chunk with a dictionary) in its workspace.  A selection whose records exceed `ws_limit`
+    The C-ABI call keeps one record per chunk (histograms, token list sized for the all-literal worst case — the FULL stream
+    later overwrites it; a chunk with a dictionary has the DELTA stream's slot behind it: ~4.2 / 5.2 x the chunk) in its workspace.  A selection whose records exceed `ws_limit`
     bytes (default DEFLATE_WS_LIMIT) is encoded in consecutive pieces that each fit — same streams, same order, a bounded
     workspace whatever the shard size.
 
@@ -227,11 +231,10 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     if n_sel <= 0:
         return torch.empty(0, dtype=torch.uint8, device=dev), out_off, kind
     lens = (cuts[1:] - cuts[:-1]) if chunk_ids is None else (cuts[chunk_ids + 1] - cuts[chunk_ids])
-    # per-job record of the C-ABI workspace = hmse_l1_deflate_record_bytes(len) (histograms, token list, 16-byte aligned
-    # stream slot with 16 bytes of slack), evaluated on the device; tests/test_abi.py holds the two formulas together
-    rec = record_bytes(lens)
-    nvar = 1 if base is None else 1 + (base >= 0).to(torch.int64)
-    raw, need = (int(v) for v in torch.stack([lens.sum(), (rec * nvar).sum()]).tolist())
+    # per-chunk record of the C-ABI workspace = hmse_l1_deflate_record_bytes[_dict](len), evaluated on the device;
+    # tests/test_abi.py holds the formulas together
+    rec = record_bytes(lens, None if base is None else base >= 0)
+    raw, need = (int(v) for v in torch.stack([lens.sum(), rec.sum()]).tolist())
     cap = raw + 5 * n_sel + 64  # a stored block is the worst case
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -243,7 +246,7 @@ def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_
     else:
         # consecutive pieces of the selection whose records fit; dictionaries are named by chunk id so that a piece may
         # use a chunk of an earlier piece
-        csum = torch.cumsum(rec * nvar, 0)
+        csum = torch.cumsum(rec, 0)
         ends, lo, start = [], 0, 0
         while start < n_sel:
             e = int(torch.searchsorted(csum, torch.tensor([lo + limit], dtype=csum.dtype, device=dev), right=True).item())

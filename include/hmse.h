@@ -161,6 +161,10 @@ int hmse_l3_index_update(const uint8_t* digests_all, uint64_t n_old, uint64_t n_
  *             of its 128 hashes are small enough to matter; cleared at the start of every call, so a call depends on
  *             nothing but its arguments).  With a smaller workspace (>= 0 bytes) every hash is computed; the signatures
  *             are the same either way.
+ * The table makes the call's TIME data-dependent: it pays where 4-byte shingles repeat across chunks (text: 90 % of the
+ * lookups hit, 1.6x faster than without it); on data without repeating shingles (random bytes) the lookups are overhead and
+ * a wavefront gives up after 256 of them per pass — measured 6 % slower than a call without workspace.
+ * A caller that knows its data is incompressible passes ws_bytes = 0.
  */
 int hmse_l4_minhash(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const uint64_t* chunk_ids, uint64_t n_sel, const hmse_cfg* cfg,
@@ -199,17 +203,19 @@ int hmse_l4_lsh_update(const uint32_t* sig_all, uint64_t n_old, uint64_t n_new, 
  *   kind      DEVICE u8[n_sel]: HMSE_KIND_FULL or HMSE_KIND_DELTA
  *   status    DEVICE u32[1]: bit0 = out_cap overflow (out_off still exact), bit1 = workspace too small
  *   ws        hmse_workspace_bytes(HMSE_STAGE_L1_DEFLATE, n_sel, cfg) is the FIXED part; after it the call needs
- *             one job record per encode (FULL, plus DELTA where base >= 0) of hmse_l1_deflate_record_bytes(len)
- *             bytes each (about 5*len + 1.6 KiB)
+ *             one record per chunk: hmse_l1_deflate_record_bytes(len) bytes (about 4*len + 1.4 KiB: histograms and a
+ *             token list sized for the all-literal case, which the FULL stream later overwrites), or
+ *             hmse_l1_deflate_record_bytes_dict(len) where base >= 0 (len + 21 more: the DELTA stream's own slot)
  */
 int hmse_l1_deflate(const uint8_t* data, uint64_t n, const uint64_t* cuts,
                     const uint64_t* chunk_ids, const int64_t* base, uint64_t n_sel,
                     const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap, uint64_t* out_off,
                     uint8_t* kind, uint32_t* status, void* ws, size_t ws_bytes, void* stream);
 
-/* Bytes of workspace one encode of a chunk of `chunk_len` bytes needs behind the fixed part (0 if chunk_len > 32768:
- * such a chunk cannot be encoded — `uint16_t length`, README.md:1267). */
+/* Bytes of workspace the record of a chunk of `chunk_len` bytes needs behind the fixed part — without / with a dictionary
+ * (0 if chunk_len > 32768: such a chunk cannot be encoded — `uint16_t length`, README.md:1267). */
 uint64_t hmse_l1_deflate_record_bytes(uint32_t chunk_len);
+uint64_t hmse_l1_deflate_record_bytes_dict(uint32_t chunk_len);
 
 /*
  * L1 with options (the streaming front end): as hmse_l1_deflate, plus

@@ -43,18 +43,26 @@ def test_library_exports_nothing_but_the_declared_abi():
 
 
 def test_deflate_record_bytes_formula_matches_the_abi():
-    """ops.record_bytes (evaluated on the device for a whole shard) == hmse_l1_deflate_record_bytes for every chunk length,
-    the slot is 16-byte aligned and leaves 16 bytes behind the largest stream (the encode kernel's 16-byte copy-out)."""
+    """ops.record_bytes (evaluated on the device for a whole shard) == hmse_l1_deflate_record_bytes[_dict] for every chunk
+    length; the FULL stream (copied out in whole 16-byte stores) fits the token area it overwrites, the DELTA slot behind
+    the tokens is 16-byte aligned and leaves 16 bytes behind the largest stream."""
     import torch
     from hmse_amd import _lib, ops
     lib = _lib.hip_lib()
     lens = torch.arange(0, 32769, dtype=torch.int64)
     got = ops.record_bytes(lens).numpy()
+    got_d = ops.record_bytes(lens, torch.ones_like(lens, dtype=torch.bool)).numpy()
+    mixed = ops.record_bytes(lens, lens % 2 == 1).numpy()
     want = np.array([lib.hmse_l1_deflate_record_bytes(int(v)) for v in range(32769)], dtype=np.int64)
-    assert np.array_equal(got, want)
-    slot = 1296 + 4 * ((lens.numpy() + 3) & ~3)
-    assert (slot % 16 == 0).all() and (want - slot - (lens.numpy() + 5) >= 16).all() and (want % 256 == 0).all()
-    assert lib.hmse_l1_deflate_record_bytes(32769) == 0
+    want_d = np.array([lib.hmse_l1_deflate_record_bytes_dict(int(v)) for v in range(32769)], dtype=np.int64)
+    assert np.array_equal(got, want) and np.array_equal(got_d, want_d)
+    assert np.array_equal(mixed, np.where(np.arange(32769) % 2 == 1, want_d, want))
+    L = lens.numpy()
+    body = 1296 + 4 * ((L + 3) & ~3)
+    assert (body % 16 == 0).all() and (want >= body).all() and (want % 256 == 0).all() and (want_d % 256 == 0).all()
+    assert (((L[1:] + 5 + 15) & ~15) <= body[1:] - 1296).all()          # FULL stream over the tokens, 16-byte stores
+    assert (want_d - body - (L + 5) >= 16).all()                        # DELTA slot
+    assert lib.hmse_l1_deflate_record_bytes(32769) == 0 and lib.hmse_l1_deflate_record_bytes_dict(32769) == 0
 
 
 def test_cfg_default_matches_oracle_and_dataclass(orc):
