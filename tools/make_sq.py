@@ -21,7 +21,7 @@ WAVES_PER_SIMD = {"l1_deflate_kernel (match)": 8, "l4_minhash_kernel": 8, "l1_en
 out = {"source": "rocprofv3 --pmc, two passes at 2 GB (tools/profile_round.sh); valu_active_per_wave_cycle = SQ_ACTIVE_INST_VALU / "
                  "SQ_WAVE_CYCLES (share of a resident wave's cycles with one of ITS vector instructions executing); x resident waves per "
                  "SIMD = valu_busy_per_simd, the SIMD's VALU utilisation (1.0 = the vector ALU never idles); *_per_valu = instruction mix",
-       "round": 2, "kernels": {}}
+       "round": 3, "kernels": {}}
 for name, f in sorted(fam.items()):
     wc = f.get("SQ_WAVE_CYCLES", 0.0)
     e = {}

@@ -49,7 +49,7 @@ def main():
                      "--steps 1 --warmup 0; per launch: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of a wide "
                      "coalesced read, /opt/skills/guides/MI355X_MICROARCH.md HBM section; exact for l2_hash_kernel's 16-B/lane stream, "
                      "uncalibrated for per-lane 64-B blocks such as l3_sha256_kernel's, where the raw value already equals the algorithmic bytes)",
-           "total_bytes": total, "round": 2, "kernels": {}}
+           "total_bytes": total, "round": 3, "kernels": {}}
     for k in sorted(set(fe) | set(wr)):
         f, nf = fe.get(k, (0.0, 0))
         w, nw = wr.get(k, (0.0, 0))
