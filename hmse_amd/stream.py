@@ -22,11 +22,14 @@ from .ingest import ShardResult, shard_stats
 
 class StreamIngest:
     def __init__(self, cfg: IngestConfig, capacity_bytes: int, device, max_chunks: int | None = None, graph: bool = False,
-                 stream_capacity: int | None = None):
+                 stream_capacity: int | None = None, poll_status_every: int = 0):
         """graph=True: every batch runs as ONE enqueue of the device-count chain (hmse_stream_batch: no host read between
         stages); from the second batch of a given size on, that enqueue is a replay of a hipGraph captured once for the size.
         Results are identical to graph=False.  stream_capacity: bytes reserved for the DEFLATE streams in that mode
-        (default: half the corpus capacity + 64 MiB; overflow is reported, never written)."""
+        (default: half the corpus capacity + 64 MiB; overflow is reported, never written).  poll_status_every = N > 0 (graph
+        mode): after every N-th batch the chain's sticky status word is copied to pinned host memory WITHOUT waiting for it; a
+        later push() that finds the copy complete and non-zero raises then instead of at finish() — a failed batch and all
+        later ones are no-ops on the device either way, the poll only tells a long stream early."""
         if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
             raise ValueError("StreamIngest runs the full L1-L4 pipeline")
         self.cfg, self.dev = cfg, device
@@ -58,6 +61,9 @@ class StreamIngest:
         self.n_chunks = 0
         self.n_unique = 0
         self.stream_bytes = 0
+        self.poll_status_every = int(poll_status_every)
+        self._polls: list[tuple[torch.Tensor, torch.cuda.Event, int]] = []   # (pinned status word, copy-done event, batch number)
+        self._n_chain_batches = 0
         self.stream_parts: list[torch.Tensor] = []
         self._ws = None             # DEFLATE workspace, kept across batches
         self.graph = bool(graph)
@@ -151,6 +157,7 @@ class StreamIngest:
         """Issue the host -> HBM copy of the next batch (asynchronous when the tensor is pinned), then process every
         batch whose copy was issued earlier: the copy of this batch overlaps the kernels of the previous one."""
         n = host_batch.numel()
+        self._check_polls()
         if self.n_bytes % self.cfg.seg_size:
             raise ValueError("only the last batch may be a partial segment")
         if self.n_bytes + n > self.data.numel():
@@ -220,6 +227,22 @@ class StreamIngest:
                 self._graphs[n] = (g, ws, seg_off)
             g.replay()          # ... and from then on every batch of this size is one graph launch
         self.n_done = off + n
+        self._n_chain_batches += 1
+        if self.poll_status_every and self._n_chain_batches % self.poll_status_every == 0:
+            host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            host.copy_(self._state[7:8], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._polls.append((host, ev, self._n_chain_batches))
+
+    def _check_polls(self) -> None:
+        """Completed status polls (never waits): raise on the first non-zero one."""
+        while self._polls and self._polls[0][1].query():
+            host, _, nb = self._polls.pop(0)
+            st = int(host.item())
+            if st:
+                raise ValueError(f"streaming chain status {st:#x} (polled after batch {nb}): bit0 chunk capacity, bit1 stored-chunk capacity, "
+                                 "bit2 L2, bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped")
 
     # ------------------------------------------------------------------ one batch, host-sized launches (graph=False)
     def _process(self, off: int, n: int, copied: torch.cuda.Event) -> None:
@@ -254,7 +277,7 @@ class StreamIngest:
         base_chunk = torch.where(base_new >= 0, self._uniq[base_new.clamp(min=0)], base_new)
         # one workspace for every batch, sized for the worst case of this batch (every chunk stored, every one with a dictionary):
         # a fresh multi-GB allocation per batch synchronises the device and stalls the copy/compute overlap
-        worst = 2 * (5 * n + 1600 * n_new) + ops.workspace_bytes(ops.STAGE_DEFLATE, n_new, cfg) + (1 << 20)
+        worst = (5 * n + 1600 * n_new) + ops.workspace_bytes(ops.STAGE_DEFLATE, n_new, cfg) + (1 << 20)
         if self._ws is None or self._ws.numel() < worst:
             self._ws = None
             self._ws = torch.empty(worst, dtype=torch.uint8, device=dev)

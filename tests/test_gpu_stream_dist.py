@@ -296,3 +296,26 @@ def test_world_size_1_stream_with_the_rccl_all_gather_between_the_graph_replays(
     assert e[1] is not None and e[2] is not None and e[3] == 5
     for name in NAMES:
         assert torch.equal(getattr(res, name), getattr(whole, name)), name
+
+
+def test_status_poll_reports_a_dropped_batch_before_finish(dev):
+    """StreamIngest(poll_status_every=1): the sticky status word travels to pinned host memory behind every batch without a wait;
+    once such a copy has completed, the next push() raises — a long stream learns of a dropped batch early."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ingest, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(8 << 20, seed=5)
+    B = 2 << 20
+    n1 = ingest.ingest_shard(torch.from_numpy(data[:B]).to(dev), cfg).cuts.numel() - 1
+    s = stream.StreamIngest(cfg, data.size, dev, graph=True, max_chunks=n1 + 10, poll_status_every=1)
+    s.push(torch.from_numpy(data[:B].copy()))
+    s.push(torch.from_numpy(data[B: 2 * B].copy()))          # processes batch 1 (fits)
+    s.push(torch.from_numpy(data[2 * B: 3 * B].copy()))      # processes batch 2: dropped on the device, status bit 0
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="polled after batch 2"):
+        s.push(torch.from_numpy(data[3 * B:].copy()))
+    ok = stream.StreamIngest(cfg, data.size, dev, graph=True, poll_status_every=1)
+    for a in range(0, data.size, B):
+        ok.push(torch.from_numpy(data[a: a + B].copy()))
+    res = ok.finish()
+    assert int(res.cuts[-1]) == data.size and not ok._polls or all(int(h.item()) == 0 for h, _, _ in ok._polls)
