@@ -1324,23 +1324,27 @@ static_assert(2 * Layout<NT_S, TCAP_S2, TCAP_S2, true, true>::TOTAL <= 160 * 102
 static_assert(2 * Layout<NT_S, TCAP_SG, TCAP_SG, true, true, true>::TOTAL <= 160 * 1024, "class SG must fit twice per CU");
 static_assert(2 * Layout<NT_S, TCAP_SG2, TCAP_SG2, true, true, true, true>::TOTAL <= 160 * 1024, "class SG2 must fit twice per CU");
 
-// wave-aggregated append of `job` to list `cl` (one atomic per list per wavefront instead of one per job); all lanes call it
-__device__ __forceinline__ void list_append(bool on, uint32_t cl, uint32_t job, uint32_t* lists, uint64_t list_stride, uint32_t* counts) {
-#pragma unroll 1
-  for (uint32_t c = 0; c < (uint32_t)N_LIST; c++) {
-    const uint64_t m = __ballot(on && cl == c);
-    if (m == 0) continue;
-    uint32_t base0 = 0;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-    if (lane_id() == leader) base0 = atomicAdd(&counts[c], (uint32_t)__builtin_popcountll(m));
-    base0 = (uint32_t)__builtin_amdgcn_readlane((int)base0, (int)leader);
-    if (on && cl == c) lists[(size_t)c * list_stride + base0 + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = job;
-  }
+// workgroup-aggregated append of up to two jobs per thread to their lists: LDS counters, then ONE global atomic per list and
+// workgroup (per wavefront before: 88 k same-address atomics per 10 GB shard on a handful of counters, 1.7 ms).  All threads call it.
+constexpr int LIST_NT = 1024;
+__device__ __forceinline__ void list_append2(bool on1, uint32_t c1, uint32_t job1, bool on2, uint32_t c2, uint32_t job2,
+                                             uint32_t* lists, uint64_t list_stride, uint32_t* counts) {
+  __shared__ uint32_t s_cnt[N_LIST], s_base[N_LIST];
+  if (threadIdx.x < (uint32_t)N_LIST) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t i1 = 0, i2 = 0;
+  if (on1) i1 = atomicAdd(&s_cnt[c1], 1u);
+  if (on2) i2 = atomicAdd(&s_cnt[c2], 1u);
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)N_LIST) { const uint32_t n = s_cnt[threadIdx.x]; s_base[threadIdx.x] = n ? atomicAdd(&counts[threadIdx.x], n) : 0u; }
+  __syncthreads();
+  if (on1) lists[(size_t)c1 * list_stride + s_base[c1] + i1] = job1;
+  if (on2) lists[(size_t)c2 * list_stride + s_base[c2] + i2] = job2;
 }
 
 // job = (k << 1) | variant, appended to its size class's list.  A chunk with a base gets a dictionary job (its DELTA record)
 // and nothing else in this pass; a chunk without one a plain job (its FULL record).
-__global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
+__global__ __launch_bounds__(LIST_NT) void classify_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                         const int64_t* __restrict__ base, uint64_t n_sel, uint32_t base_is_chunk,
                                                         uint32_t* __restrict__ lists, uint64_t list_stride, uint32_t* __restrict__ counts,
                                                         const uint64_t* __restrict__ n_dev) {
@@ -1359,14 +1363,13 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint64_t* __restric
     }
   }
   const bool enc_ok = in && L <= 32768;
-  list_append(in && !hasb, size_class(L), (uint32_t)(k << 1), lists, list_stride, counts);
-  list_append(in && hasb, dict_list(size_class(L + Dl)), (uint32_t)((k << 1) | 1u), lists, list_stride, counts);
-  list_append(enc_ok && !hasb, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
-  list_append(enc_ok && hasb, L <= 12288 ? 15u : 16u, (uint32_t)((k << 1) | 1u), lists, list_stride, counts);
+  const uint32_t job = (uint32_t)(k << 1) | (hasb ? 1u : 0u);
+  list_append2(in, hasb ? dict_list(size_class(L + Dl)) : size_class(L), job,
+               enc_ok, hasb ? (L <= 12288 ? 15u : 16u) : (L <= 12288 ? 6u : 7u), job, lists, list_stride, counts);
 }
 
 // rule 7: chunks with a base whose delta is no quick accept need their FULL record after all — they join the plain lists
-__global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
+__global__ __launch_bounds__(LIST_NT) void redo_kernel(const uint64_t* __restrict__ cuts, const uint64_t* __restrict__ chunk_ids,
                                                     const int64_t* __restrict__ base, uint64_t n_sel, const uint32_t* __restrict__ len_delta,
                                                     uint32_t pct, uint32_t* __restrict__ lists, uint64_t list_stride,
                                                     uint32_t* __restrict__ counts, const uint64_t* __restrict__ n_dev) {
@@ -1378,8 +1381,7 @@ __global__ __launch_bounds__(256) void redo_kernel(const uint64_t* __restrict__ 
     L = cuts[c + 1] - cuts[c];
     redo = !delta_quick(len_delta[k], L, pct);
   }
-  list_append(redo, size_class(L), (uint32_t)(k << 1), lists, list_stride, counts);
-  list_append(redo && L <= 32768, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
+  list_append2(redo, size_class(L), (uint32_t)(k << 1), redo && L <= 32768, L <= 12288 ? 6u : 7u, (uint32_t)(k << 1), lists, list_stride, counts);
 }
 
 // record sizes (one record per chunk; a chunk with a dictionary has the DELTA stream's slot behind its tokens)
@@ -1625,7 +1627,7 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   rec_size_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.rec_off, n_dev);
   HMSE_LAUNCH_CHECK();
   if (exclusive_scan_u64(w.rec_off, n_sel, w.rec_off, w.bsum, w.rec_total, stream, n_dev) != HMSE_OK) return HMSE_EHIP;
-  classify_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, a_base_is_chunk, w.lists, w.list_stride, w.counters, n_dev);
+  classify_kernel<<<dim3((uint32_t)((n_sel + LIST_NT - 1) / LIST_NT)), dim3(LIST_NT), 0, stream>>>(cuts, chunk_ids, base, n_sel, a_base_is_chunk, w.lists, w.list_stride, w.counters, n_dev);
   HMSE_LAUNCH_CHECK();
   Args a;
   a.data = data; a.n = n; a.cuts = cuts; a.chunk_ids = chunk_ids; a.base = base; a.n_sel = n_sel;
@@ -1681,7 +1683,7 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
     HMSE_DFL_LAUNCH(true, (int)dict_list(4), 18 + 4, 512, NT_S, TCAP_S2, TCAP_S2, true, true)
     HMSE_DFL_LAUNCH(true, (int)dict_list(0), 18 + 0, 512, NT_S, TCAP_S, TCAP_S, true)
     HMSE_DFL_ENCODE(15, 30, 16, 31)
-    redo_kernel<<<dim3(blocks), dim3(256), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_delta, cfg->delta_max_ratio_pct, w.lists, w.list_stride,
+    redo_kernel<<<dim3((uint32_t)((n_sel + LIST_NT - 1) / LIST_NT)), dim3(LIST_NT), 0, stream>>>(cuts, chunk_ids, base, n_sel, w.len_delta, cfg->delta_max_ratio_pct, w.lists, w.list_stride,
                                                         w.counters, n_dev);
     HMSE_LAUNCH_CHECK();
   }
