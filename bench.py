@@ -222,6 +222,10 @@ def main():
     distributed = world > 1 or os.environ.get("HMSE_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "RANK" not in os.environ:   # HMSE_BENCH_FORCE_DIST=1 under plain `python bench.py`: a rendezvous of one
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         if rehearse:
             dist.init_process_group("gloo")
         else:
