@@ -67,6 +67,8 @@ def gather_rows(rows: torch.Tensor, group=None):
     dist.all_gather_into_tensor(counts, n_loc, group=group)
     cl = counts.tolist()
     mx = max(cl)
+    if mx == 0:      # nobody has a row (every rank knows it from the counts): no second collective
+        return rows.to(dev)[:0], 0, 0, [0] * world
     padded = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=xdev)
     padded[: rows.shape[0]] = rows.to(xdev)
     allp = torch.empty((world * mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=xdev)
@@ -104,9 +106,19 @@ def fetch_chunks(req: torch.Tensor, u_bases: list, data: torch.Tensor, cuts: tor
     `gather(out_cuts, chunk_ids, cuts, data)` stands in for the HIP gather in the gloo test of the exchange itself."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    counts, local_idx = route_requests(req, u_bases, world)
+    return fetch_chunks_routed(counts, local_idx, data, cuts, uniq_ids, group, gather)
+
+
+def fetch_chunks_routed(counts: torch.Tensor, local_idx: torch.Tensor, data: torch.Tensor, cuts: torch.Tensor, uniq_ids: torch.Tensor,
+                        group=None, gather=None):
+    """fetch_chunks() with the routing done by the caller: `counts[r]` requests go to rank r, `local_idx` holds the owners' local
+    stored-chunk indices grouped by owner in rank order (a multi-rank STREAM's stored chunks interleave in the global numbering, so
+    the owner is looked up, not computed from a base table: stream_dist.GlobalL4StreamIngest).  Returns (bytes, lens) in that order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
     dev = data.device
     xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
-    counts, local_idx = route_requests(req, u_bases, world)
     want = counts.to(xdev)
     asked = torch.empty(world, dtype=torch.int64, device=xdev)
     dist.all_to_all_single(asked, want, group=group)                    # how many chunks each rank asks of me

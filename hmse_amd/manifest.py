@@ -133,6 +133,8 @@ def remote_base_table(res) -> np.ndarray | None:
     """DELTA records of a global-L4 shard whose dictionary is stored on another shard: (slot, shard, that shard's slot).
     Their DeltaChunk headers are packed unresolved (base_lba 0xFFFFFFFF); merge_manifests() fills them in."""
     import torch
+    if hasattr(res, "remote_bases"):      # a global-L4 STREAM's shard: its stored chunks interleave with the other ranks' in the
+        return res.remote_bases           # global numbering, the owner table comes with the result (stream_dist.GlobalL4StreamIngest)
     bg = getattr(res, "base_global", None)
     if bg is None:
         return None
@@ -206,11 +208,12 @@ def merge_manifests(parts: list) -> Store:
             ptrs["flags"][rec] = KIND_POINTER | (int(r) << 4)
         blob = m.blob
         if m.n_remote():
-            # DeltaChunk headers whose dictionary lives in an earlier shard's blob: {base_lba, base_length} from that shard's index
+            # DeltaChunk headers whose dictionary lives in another shard's blob (an earlier one; any other one in a stream's store): {base_lba, base_length} from that shard's index
             # (which shard: the manifest's remote_bases table — the 8-byte header has no room for it)
             blob = m.blob.copy()
             rb = m.remote_bases
-            assert (rb["shard"] < m.shard).all(), "a dictionary is always an EARLIER stored chunk"
+            assert ((rb["shard"] < m.shard) | ((rb["shard"] != m.shard) & (m.pieces is not None))).all(), \
+                "a dictionary is always an EARLIER stored chunk (the shards of a stream interleave: any other shard)"
             for r in np.unique(rb["shard"]):
                 t = parts[int(r)]
                 sel = rb[rb["shard"] == r]

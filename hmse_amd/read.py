@@ -50,6 +50,8 @@ def reconstruct_shards(results: list, verify: bool = True) -> list:
     DELTA record's dictionary — named by its global stored-chunk index — is any earlier record; then every shard's chunks
     are laid out from the slots their first occurrences name.  Returns the shards' data tensors, in order."""
     dev = results[0].cuts.device
+    if all(getattr(r, "ug", None) is not None for r in results):
+        return _reconstruct_stream_global_l4(results, verify)
     u_counts = [int(r.uniq_ids.numel()) for r in results]
     u_bases = [sum(u_counts[:i]) for i in range(len(results))]
     lens_u, offs, run = [], [], 0
@@ -80,6 +82,40 @@ def reconstruct_shards(results: list, verify: bool = True) -> list:
         slots = slot_of_global[fo]
         if bool((slots < 0).any()):
             raise ReadError("a first occurrence is not a stored chunk of any shard")
+        d = ops.read_assemble(r.cuts, slots, raw_off, raw)
+        if verify and r.digests is not None:
+            verify_digests(d, r.cuts, r.digests)
+        out.append(d)
+    return out
+
+
+def _reconstruct_stream_global_l4(results: list, verify: bool) -> list:
+    """reconstruct_shards for the ranks of a global-L4 STREAM (stream_dist.GlobalL4StreamIngest): `res.ug` names every stored
+    chunk's GLOBAL stored index in stream order and `res.base_global` a dictionary by that index — which may belong to any rank,
+    also a later-numbered one — so the records of all ranks are decoded in that order (a dictionary then always precedes)."""
+    dev = results[0].cuts.device
+    starts, slens, lens_u, run = [], [], [], 0
+    for r in results:
+        ln = r.cuts[1:] - r.cuts[:-1]
+        lens_u.append(ln[r.uniq_ids]); starts.append(r.stream_off[:-1] + run); slens.append(r.stream_off[1:] - r.stream_off[:-1])
+        run += int(r.streams.numel())
+    ug = torch.cat([r.ug for r in results])
+    u = ug.numel()
+    order = torch.argsort(ug)
+    if not torch.equal(ug[order], torch.arange(u, dtype=torch.int64, device=dev)):
+        raise ReadError("the ranks' stored chunks do not tile the global stored order")
+    pick = lambda parts: torch.cat(parts)[order]
+    raw, raw_off, _ = ops.l1_inflate(torch.cat([r.streams for r in results]), pick(starts), pick([r.kind for r in results]),
+                                     pick([r.base_global for r in results]), pick(lens_u), stream_len=pick(slens).to(torch.int32))
+    n_global = results[0].n_global
+    slot_of_global = torch.full((n_global,), -1, dtype=torch.int64, device=dev)
+    for r in results:
+        slot_of_global[r.gidx[r.uniq_ids]] = r.ug
+    out = []
+    for r in results:
+        slots = slot_of_global[r.first_occ]
+        if bool((slots < 0).any()):
+            raise ReadError("a first occurrence is not a stored chunk of any rank")
         d = ops.read_assemble(r.cuts, slots, raw_off, raw)
         if verify and r.digests is not None:
             verify_digests(d, r.cuts, r.digests)
@@ -140,6 +176,28 @@ def parse_manifest(m: Manifest) -> dict:
     return {"kind": slot_kind, "base": base, "base_shard": base_shard, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
 
 
+def dependency_order(base: np.ndarray):
+    """Records in (shard, slot) order with `base[k]` = the record holding k's dictionary (-1 none).  hmse_l1_inflate wants a
+    dictionary to PRECEDE its dependants; that holds as stored except in the store of a multi-rank stream ingested with global L4,
+    where a dictionary may sit on a later-numbered shard.  -> None if base[k] < k everywhere, else (order, new_of_old): records
+    sorted by dictionary depth (stable), and the inverse map."""
+    n = len(base)
+    if n == 0 or (base < np.arange(n)).all():
+        return None
+    depth = np.zeros(n, np.int64)
+    for _ in range(n):
+        nd = np.where(base >= 0, depth[np.maximum(base, 0)] + 1, 0)
+        if np.array_equal(nd, depth):
+            break
+        depth = nd
+    else:
+        raise ReadError("the DELTA records' dictionaries form a cycle")
+    order = np.argsort(depth, kind="stable")
+    new_of_old = np.empty(n, np.int64)
+    new_of_old[order] = np.arange(n)
+    return order, new_of_old
+
+
 def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
     """A sharded store (one Manifest per shard, cross-shard pointers resolved by manifest.merge_manifests) -> the
     original corpus in global chunk order, decoded on `device`: the records of all shards are inflated in one call, then
@@ -162,15 +220,19 @@ def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
             if not np.array_equal(lba, want):
                 raise ReadError("the store has unresolved cross-shard DeltaChunk headers: merge_manifests() its shards first")
     cat = lambda key, adj=None: np.concatenate([(p[key] if adj is None else adj(i, p)) for i, p in enumerate(ps)]) if ps else np.zeros(0, np.int64)
-    base_g = cat("base", lambda i, p: np.where(p["base"] >= 0, sb[p["base_shard"]] + p["base"], -1))
+    base_g = cat("base", lambda i, p: np.where(p["base"] >= 0, sb[p["base_shard"]] + p["base"], -1)).astype(np.int64)
+    dep = dependency_order(base_g)          # (a global-L4 stream's store: dictionaries on later-numbered shards)
+    o = (lambda a: a) if dep is None else (lambda a: a[dep[0]])
+    if dep is not None:
+        base_g = np.where(base_g >= 0, dep[1][np.maximum(base_g, 0)], -1)
     if len(base_g):
         blobs = [t(m.blob, torch.uint8) for m in store.shards if m.blob.size]
         blob_all = blobs[0] if len(blobs) == 1 else torch.cat(blobs) if blobs else torch.zeros(1, dtype=torch.uint8, device=device)
         del blobs
         raw_all, raw_off_all, _ = ops.l1_inflate(blob_all,
-                                                 t(cat("stream_off", lambda i, p: p["stream_off"] + bb[i]), torch.int64),
-                                                 t(cat("kind"), torch.uint8), t(base_g, torch.int64), t(cat("raw_len"), torch.int64),
-                                                 stream_len=t(cat("stream_len"), torch.int32))
+                                                 t(o(cat("stream_off", lambda i, p: p["stream_off"] + bb[i])), torch.int64),
+                                                 t(o(cat("kind")), torch.uint8), t(o(base_g), torch.int64), t(o(cat("raw_len")), torch.int64),
+                                                 stream_len=t(o(cat("stream_len")), torch.int32))
     else:
         raw_all = torch.empty(0, dtype=torch.uint8, device=device); raw_off_all = torch.zeros(1, dtype=torch.int64, device=device)
     slot_g = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in store.shards]) \
@@ -182,7 +244,7 @@ def read_store(store: Store, device, verify: bool = True) -> torch.Tensor:
         slot_g, lens = slot_g[perm], lens[perm]
     cuts = torch.zeros(len(lens) + 1, dtype=torch.int64, device=device)
     torch.cumsum(t(lens, torch.int64), 0, out=cuts[1:])
-    data = ops.read_assemble(cuts, t(slot_g, torch.int64), raw_off_all, raw_all)
+    data = ops.read_assemble(cuts, t(slot_g if dep is None else dep[1][slot_g], torch.int64), raw_off_all, raw_all)
     if verify:
         sha = np.concatenate([m.index["sha256"] for m in store.shards]) if store.shards else np.zeros((0, 32), np.uint8)
         if len(sha) and sha.any():
@@ -232,8 +294,11 @@ class StoreReader:
         self.stream_off = cat("stream_off", lambda i, p: p["stream_off"] + bb[i]).astype(np.int64)
         self.stream_len = cat("stream_len").astype(np.int64)
         self.raw_len = cat("raw_len").astype(np.int64)
-        if len(self.base) and not (self.base < np.arange(len(self.base))).all():
-            raise ReadError("a DELTA record names a dictionary that is not an earlier record")
+        dep = dependency_order(self.base)       # records renumbered once so that a dictionary precedes its dependants
+        if dep is not None:
+            order, new_of_old = dep
+            self.base = np.where(self.base >= 0, new_of_old[np.maximum(self.base, 0)], -1)[order]
+            self.kind, self.stream_off, self.stream_len, self.raw_len = self.kind[order], self.stream_off[order], self.stream_len[order], self.raw_len[order]
         blobs = [t(m.blob, torch.uint8) for m in shards if m.blob.size]
         self.blob = blobs[0] if len(blobs) == 1 else torch.cat(blobs) if blobs else torch.zeros(1, dtype=torch.uint8, device=device)
         self.slot = np.concatenate([sb[m.chunk_map["shard"].astype(np.int64)] + m.chunk_map["slot"].astype(np.int64) for m in shards]) \
@@ -245,6 +310,8 @@ class StoreReader:
             self.slot, lens = self.slot[perm], lens[perm]
         self.cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)          # chunk map: byte offset of every chunk
         self.sha = np.concatenate([m.index["sha256"] for m in shards]) if shards else np.zeros((0, 32), np.uint8)
+        if dep is not None:
+            self.slot, self.sha = new_of_old[self.slot], self.sha[order]
         self.n_bytes = int(self.cuts[-1])
         self.last = {}
 

@@ -291,6 +291,9 @@ def store_results(results: list, only: int | None = None) -> list:
         pieces["n"] = ends - starts
         rr = dataclasses.replace(r, first_occ=to_store[r.first_occ], chunk_base=vb, shard_bases=list(vbase))
         rr.gidx, rr.pieces = r.gidx, pieces
+        for extra in ("ug", "remote_bases"):          # a global-L4 stream's shard (GlobalL4StreamIngest)
+            if hasattr(r, extra):
+                setattr(rr, extra, getattr(r, extra))
         out.append(rr)
     return out
 
@@ -308,3 +311,288 @@ def gather_global_index(res, group=None):
     for r in range(world):
         out.append(res if r == dist.get_rank(group) else types.SimpleNamespace(gidx=allg[bases[r]: bases[r + 1], 0], n_global=res.n_global, cuts=res.cuts))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Global L4 for a multi-rank stream ("cross-GPU base-chunk fetch over xGMI for global L4 (config 5)")
+# ---------------------------------------------------------------------------------------------------------------------------
+class GlobalL4StreamIngest:
+    """This rank's side of a multi-rank stream whose L4 base selection spans ALL ranks (README.md:1375-1383 against one band
+    table): besides the digests, every batch all-gathers the signatures of its newly stored chunks; every rank keeps the same
+    band tables over the GLOBAL stored-chunk order (batch, rank, local) and so finds the same bases as a one-rank run; a base
+    stored on another rank is fetched over xGMI (three all-to-alls, ingest.fetch_chunks_routed) into a ghost area behind the
+    rank's data, where the DEFLATE kernel addresses it by chunk id.  Dedupe AND dictionaries are then those of the one-rank
+    stream: the records of all ranks, put in global stored order, are bit-identical to its records.
+
+    Per batch the host sizes three ragged exchanges, so this path is enqueued stage by stage (no hipGraph); the shard-local
+    DistStreamIngest stays the captured fast path.  The stages are methods so that tests/ can drive several ranks in lock step on
+    one GPU (stream_shards_local_global_l4): stage_hash -> [digests of all ranks] -> stage_index -> [signatures of all ranks] ->
+    stage_lsh -> [ghost chunks] -> stage_encode.
+
+    finish() -> ShardResult with: gidx (local chunk -> global chunk), ug (local stored slot -> global stored index), base (local
+    slot of the dictionary, -1 if none or remote), base_global (GLOBAL STORED index of the dictionary in stream order, -1 none),
+    remote_bases ((slot, owner rank, owner's slot) table for manifest.build_manifest)."""
+
+    def __init__(self, cfg: IngestConfig, capacity_bytes: int, piece_bytes: int, device, world: int, rank: int, group=None,
+                 max_chunks: int | None = None, max_chunks_global: int | None = None, ghost_bytes: int | None = None):
+        if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
+            raise ValueError("GlobalL4StreamIngest runs the full L1-L4 pipeline")
+        if piece_bytes <= 0 or piece_bytes % cfg.seg_size:
+            raise ValueError("piece_bytes (the nominal piece size) must be a positive multiple of seg_size")
+        if not 0 <= rank < world <= 256:
+            raise ValueError("0 <= rank < world <= 256")
+        self.cfg, self.dev, self.world, self.rank, self.group = cfg, device, int(world), int(rank), group
+        self.capacity = int(capacity_bytes)
+        self.ghost_cap = int(ghost_bytes if ghost_bytes is not None else 2 * piece_bytes)
+        self.data = torch.empty(self.capacity + self.ghost_cap, dtype=torch.uint8, device=device)   # [0, capacity): this rank's pieces; behind: ghosts
+        self.n_bytes = 0
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.pending: list = []
+        per = max(1, cfg.avg_size // 2)
+        self.max_chunks = int(max_chunks or (capacity_bytes // per + capacity_bytes // cfg.seg_size + 64))
+        self.max_chunks_g = int(max_chunks_global or self.max_chunks * world)
+        mc, mg = self.max_chunks, self.max_chunks_g
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        self._cuts = z(mc + 1, torch.int64)
+        self._gidx = z(mc, torch.int64)
+        self.n_chunks = 0
+        # this rank's stored chunks (appended per batch)
+        self._uniq, self._ug, self._base, self._base_global, self._kind, self._sig_l, self._keys_l = [], [], [], [], [], [], []
+        self._stream_parts, self._stream_lens = [], []
+        self.n_unique = 0
+        # the global index and the global band tables: identical on every rank
+        self._digests_g = torch.empty((mg, 32), dtype=torch.uint8, device=device)
+        self._first_occ_g = z(mg, torch.int64)
+        self._refcount_g = z(mg, torch.int32)
+        self._l3_table = torch.empty(ops.l3_index_slots(mg), dtype=torch.int32, device=device)
+        self._mug = min(mg, 1 << 23)
+        self._sig_g = torch.empty((self._mug, cfg.n_hashes), dtype=torch.int32, device=device)
+        self._keys_g = z((self._mug, cfg.bands), torch.int32)
+        self._base_g = z(self._mug, torch.int64)
+        self._lsh_tables = torch.empty((cfg.bands, ops.l4_lsh_slots(self._mug)), dtype=torch.int32, device=device)
+        self._g_owner = z(self._mug, torch.int64)     # global stored chunk -> owning rank, that rank's stored slot
+        self._g_local = z(self._mug, torch.int64)
+        ops.l3_index_update(self._digests_g, 0, 0, self._first_occ_g, self._refcount_g, self._l3_table)
+        ops.l4_lsh_update(self._sig_g, 0, 0, cfg, self._keys_g, self._base_g, self._lsh_tables)
+        self.n_global = 0
+        self.u_global = 0
+        self.u_counts = [0] * self.world
+        self._ws = None
+        self.n_batches = 0
+        self.remote_dictionaries = 0
+        self.ghost_bytes_fetched = 0
+
+    # ------------------------------------------------------------------ the four stages of one batch
+    def stage_hash(self, off: int, n: int) -> torch.Tensor:
+        """L2 + L3 of this rank's piece (bytes [off, off + n) of its data): cuts appended, -> digests uint8[n_b, 32]."""
+        n_old = self.n_chunks
+        if n:
+            cuts_b = ops.l2_cdc(self.data[off: off + n], self.cfg)
+            n_b = cuts_b.numel() - 1
+            if n_old + n_b > self.max_chunks:
+                raise ValueError("stream index capacity exceeded (max_chunks)")
+            self._cuts[n_old + 1: n_old + n_b + 1] = cuts_b[1:] + off
+            dg = ops.l3_sha256(self.data[: off + n], self._cuts[n_old: n_old + n_b + 1])
+        else:
+            n_b, dg = 0, torch.empty((0, 32), dtype=torch.uint8, device=self.dev)
+        self._cur = dict(off=off, n=n, n_old=n_old, n_b=n_b)
+        return dg
+
+    def stage_index(self, all_digests: torch.Tensor, counts: list) -> torch.Tensor:
+        """The batch's digests of ALL ranks (rank order) join the global index; -> signatures int32[u_b, 128] of the chunks THIS
+        rank stores (first occurrences in global order)."""
+        c = self._cur
+        g_old, g_new = self.n_global, int(sum(counts))
+        if g_old + g_new > self.max_chunks_g:
+            raise ValueError("global index capacity exceeded (max_chunks_global)")
+        self._digests_g[g_old: g_old + g_new] = all_digests
+        ops.l3_index_update(self._digests_g, g_old, g_new, self._first_occ_g, self._refcount_g, self._l3_table)
+        mine0 = g_old + int(sum(counts[: self.rank]))
+        g = torch.arange(mine0, mine0 + c["n_b"], dtype=torch.int64, device=self.dev)
+        self._gidx[c["n_old"]: c["n_old"] + c["n_b"]] = g
+        uniq_new = c["n_old"] + (self._first_occ_g[mine0: mine0 + c["n_b"]] == g).nonzero().flatten()
+        self.n_global = g_old + g_new
+        self.n_chunks = c["n_old"] + c["n_b"]
+        c["uniq_new"] = uniq_new
+        end = c["off"] + c["n"]
+        c["sig"] = ops.l4_minhash(self.data[:end], self._cuts[: self.n_chunks + 1], self.cfg, uniq_new) if uniq_new.numel() else \
+            torch.empty((0, self.cfg.n_hashes), dtype=torch.int32, device=self.dev)
+        return c["sig"]
+
+    def stage_lsh(self, all_sigs: torch.Tensor, counts_u: list):
+        """The batch's signatures of ALL ranks (rank order) join the global band tables; this rank's bases are resolved.
+        -> (counts per owner rank, owners' local stored slots grouped by owner): the remote dictionaries to fetch."""
+        c = self._cur
+        u_old, u_new = self.u_global, int(sum(counts_u))
+        if u_old + u_new > self._mug:
+            raise ValueError("global stored-chunk capacity exceeded")
+        if u_new:
+            self._sig_g[u_old: u_old + u_new] = all_sigs
+            o = u_old
+            for r, cnt in enumerate(counts_u):
+                if cnt:
+                    self._g_owner[o: o + cnt] = r
+                    self._g_local[o: o + cnt] = torch.arange(self.u_counts[r], self.u_counts[r] + cnt, dtype=torch.int64, device=self.dev)
+                    self.u_counts[r] += cnt
+                    o += cnt
+            ops.l4_lsh_update(self._sig_g, u_old, u_new, self.cfg, self._keys_g, self._base_g, self._lsh_tables)
+        self.u_global = u_old + u_new
+        m0 = u_old + int(sum(counts_u[: self.rank]))
+        u_b = int(counts_u[self.rank])
+        bg = self._base_g[m0: m0 + u_b].clone()
+        has = bg >= 0
+        own = has & (self._g_owner[bg.clamp(min=0)] == self.rank)
+        remote = has & ~own
+        c.update(m0=m0, u_b=u_b, bg=bg, own=own, remote=remote)
+        req = torch.unique(bg[remote])                                     # ascending global stored indices
+        owner = self._g_owner[req]
+        perm = torch.argsort(owner, stable=True)                            # grouped by owner, ascending inside a group
+        c["req"] = req[perm]
+        counts = torch.bincount(owner, minlength=self.world)[: self.world]
+        return counts, self._g_local[c["req"]]
+
+    def serve(self, local_slots: torch.Tensor):
+        """Raw bytes of this rank's stored chunks `local_slots` (what fetch_chunks_routed sends to a peer): (bytes, lens)."""
+        uniq = torch.cat(self._uniq) if self._uniq else torch.empty(0, dtype=torch.int64, device=self.dev)
+        c = getattr(self, "_cur", None)
+        if c is not None and "uniq_new" in c and not c.get("committed", False):
+            uniq = torch.cat([uniq, c["uniq_new"]])                          # (a chunk of THIS batch can already be a peer's dictionary)
+        cid = uniq[local_slots]
+        ln = self._cuts[cid + 1] - self._cuts[cid]
+        oc = torch.zeros(cid.numel() + 1, dtype=torch.int64, device=self.dev)
+        torch.cumsum(ln, 0, out=oc[1:])
+        return (ops.read_assemble(oc, cid, self._cuts, self.data) if cid.numel() else torch.empty(0, dtype=torch.uint8, device=self.dev)), ln
+
+    def stage_encode(self, ghost: torch.Tensor, ghost_lens: torch.Tensor) -> None:
+        """DEFLATE of this rank's newly stored chunks; a remote dictionary is ghost chunk j (the j-th request of stage_lsh)."""
+        c = self._cur
+        cfg, dev = self.cfg, self.dev
+        uniq_new, bg, own, remote = c["uniq_new"], c["bg"], c["own"], c["remote"]
+        gb = int(ghost.numel())
+        if gb > self.ghost_cap:
+            raise ValueError(f"a batch needs {gb} bytes of remote dictionaries, the ghost area holds {self.ghost_cap} (ghost_bytes=)")
+        uniq_all = torch.cat(self._uniq + [uniq_new]) if (self._uniq or uniq_new.numel()) else uniq_new
+        base_local = torch.where(own, self._g_local[bg.clamp(min=0)], torch.full_like(bg, -1))
+        base_chunk = torch.where(own, uniq_all[base_local.clamp(min=0)] if uniq_all.numel() else bg, torch.full_like(bg, -1))
+        cuts_x = self._cuts[: self.n_chunks + 1]
+        if c["req"].numel():
+            self.data[self.capacity: self.capacity + gb] = ghost
+            gcuts = self.capacity + torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(ghost_lens, 0)])
+            cuts_x = torch.cat([cuts_x, gcuts])                              # chunk n_chunks = the gap up to the ghost area (never named)
+            rs, inv = torch.sort(c["req"])
+            j = inv[torch.searchsorted(rs, bg.clamp(min=0)).clamp(max=rs.numel() - 1)]
+            base_chunk = torch.where(remote, self.n_chunks + 1 + j, base_chunk)
+            self.remote_dictionaries += int(remote.sum().item())
+            self.ghost_bytes_fetched += gb
+        if uniq_new.numel():
+            n_b = c["n_b"]
+            worst = (5 * c["n"] + 1600 * n_b) + ops.workspace_bytes(ops.STAGE_DEFLATE, n_b, cfg) + (1 << 20)
+            if self._ws is None or self._ws.numel() < worst:
+                self._ws = None
+                self._ws = torch.empty(worst, dtype=torch.uint8, device=dev)
+            streams, off, kind = ops.l1_deflate(self.data, cuts_x, cfg, uniq_new, base_chunk, base_is_chunk_id=True, ws=self._ws)
+            self._stream_parts.append(streams); self._stream_lens.append(off[1:] - off[:-1])
+            self._kind.append(kind)
+        self._uniq.append(uniq_new)
+        self._ug.append(torch.arange(c["m0"], c["m0"] + c["u_b"], dtype=torch.int64, device=dev))
+        self._base.append(base_local); self._base_global.append(bg)
+        self._sig_l.append(c["sig"]); self._keys_l.append(self._keys_g[c["m0"]: c["m0"] + c["u_b"]].clone())
+        self.n_unique += c["u_b"]
+        c["committed"] = True
+        self.n_batches += 1
+
+    # ------------------------------------------------------------------ N processes: the stages joined by collectives
+    def push(self, host_piece: torch.Tensor) -> None:
+        """COLLECTIVE (every rank pushes once per global batch, an empty tensor if it has no bytes in it): issue the host -> HBM
+        copy of this piece, then process the piece pushed before."""
+        n = host_piece.numel()
+        if self.n_bytes % self.cfg.seg_size:
+            raise ValueError("only a rank's last piece may end inside a segment")
+        if self.n_bytes + n > self.capacity:
+            raise ValueError("stream capacity exceeded")
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self.copy_stream):
+            if n:
+                self.data[self.n_bytes: self.n_bytes + n].copy_(host_piece, non_blocking=True)
+            ev.record(self.copy_stream)
+        while self.pending:
+            self._process(*self.pending.pop(0))
+        self.pending.append((self.n_bytes, n, ev))
+        self.n_bytes += n
+
+    def _process(self, off: int, n: int, copied) -> None:
+        from .ingest import fetch_chunks_routed, gather_rows
+        torch.cuda.current_stream().wait_event(copied)
+        dg = self.stage_hash(off, n)
+        alld, _, _, bases = gather_rows(dg, self.group)
+        counts = [b - a for a, b in zip(bases, list(bases[1:]) + [alld.shape[0]])]
+        sig = self.stage_index(alld, counts)
+        alls, _, _, ub = gather_rows(sig, self.group)
+        counts_u = [b - a for a, b in zip(ub, list(ub[1:]) + [alls.shape[0]])]
+        rc, rl = self.stage_lsh(alls, counts_u)
+        uniq_all = torch.cat(self._uniq + [self._cur["uniq_new"]])
+        ghost, glens = fetch_chunks_routed(rc, rl, self.data, self._cuts, uniq_all, self.group)
+        self.stage_encode(ghost, glens)
+
+    def finish(self) -> ShardResult:
+        while self.pending:
+            self._process(*self.pending.pop(0))
+        dev = self.dev
+        cat = lambda parts, dt, shape=(0,): torch.cat(parts) if parts else torch.empty(shape, dtype=dt, device=dev)
+        n_c = self.n_chunks
+        gidx = self._gidx[:n_c]
+        uniq = cat(self._uniq, torch.int64)
+        lens = cat(self._stream_lens, torch.int64)
+        off = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens, 0, out=off[1:])
+        base, bg = cat(self._base, torch.int64), cat(self._base_global, torch.int64)
+        kind = cat(self._kind, torch.uint8)
+        res = ShardResult(self.n_bytes, self._cuts[: n_c + 1], self._digests_g[gidx], 0, self.n_global, self._first_occ_g[gidx], self._refcount_g[gidx],
+                          uniq, cat(self._sig_l, torch.int32, (0, self.cfg.n_hashes)), cat(self._keys_l, torch.int32, (0, self.cfg.bands)), base,
+                          cat(self._stream_parts, torch.uint8), off, kind, base_global=bg)
+        res.gidx, res.ug = gidx, cat(self._ug, torch.int64)
+        import numpy as np
+        from .manifest import REMOTE_BASE_DTYPE
+        slots = ((bg >= 0) & (base < 0) & (kind == 2)).nonzero().flatten()
+        tab = np.zeros(int(slots.numel()), REMOTE_BASE_DTYPE)
+        if slots.numel():
+            tab["slot"] = slots.cpu().numpy(); tab["shard"] = self._g_owner[bg[slots]].cpu().numpy(); tab["base_slot"] = self._g_local[bg[slots]].cpu().numpy()
+        res.remote_bases = tab if len(tab) else None
+        res.stats = shard_stats(res)
+        return res
+
+
+def stream_shards_local_global_l4(batches: list, cfg: IngestConfig, world: int, device, **kw) -> list:
+    """A `world`-rank global-L4 stream with every rank on THIS GPU, in lock step: per global batch each stage of every rank, the
+    exchanges delivered as the collectives would (concatenation in rank order; remote dictionaries served by the owner's
+    `serve`).  Each result is what the rank would hold after GlobalL4StreamIngest.finish()."""
+    seg = cfg.seg_size
+    bounds = [deal_batch(b.numel(), world, seg) for b in batches]
+    pb = -(-max(max(bd[r + 1] - bd[r] for r in range(world)) for bd in bounds) // seg) * seg
+    local_total = [sum(bd[r + 1] - bd[r] for bd in bounds) for r in range(world)]
+    ranks = [GlobalL4StreamIngest(cfg, max(local_total[r], 1), pb, device, world, r, **kw) for r in range(world)]
+    for b, bd in zip(batches, bounds):
+        ns, dgs = [], []
+        for r, s in enumerate(ranks):
+            n = bd[r + 1] - bd[r]
+            if n:
+                s.data[s.n_bytes: s.n_bytes + n].copy_(b[bd[r]: bd[r + 1]])
+            ns.append(n)
+            dgs.append(s.stage_hash(s.n_bytes, n))
+        alld, counts = torch.cat(dgs), [int(d.shape[0]) for d in dgs]
+        sigs = [s.stage_index(alld, counts) for s in ranks]
+        alls, counts_u = torch.cat(sigs), [int(x.shape[0]) for x in sigs]
+        reqs = [s.stage_lsh(alls, counts_u) for s in ranks]
+        for s, (rc, rl) in zip(ranks, reqs):
+            parts, lens, o = [], [], 0
+            for owner, cnt in enumerate(rc.tolist()):
+                if cnt:
+                    by, ln = ranks[owner].serve(rl[o: o + cnt])
+                    parts.append(by); lens.append(ln); o += cnt
+            ghost = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=device)
+            glens = torch.cat(lens) if lens else torch.empty(0, dtype=torch.int64, device=device)
+            s._ghost = (ghost, glens)
+        for n, s in zip(ns, ranks):
+            s.stage_encode(*s._ghost)
+            s.n_bytes += n
+    return [s.finish() for s in ranks]

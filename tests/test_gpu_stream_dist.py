@@ -319,3 +319,137 @@ def test_status_poll_reports_a_dropped_batch_before_finish(dev):
         ok.push(torch.from_numpy(data[a: a + B].copy()))
     res = ok.finish()
     assert int(res.cuts[-1]) == data.size and not ok._polls or all(int(h.item()) == 0 for h, _, _ in ok._polls)
+
+
+# ---------------------------------------------------------------------------------------------------------------- global L4
+def oracle_whole_stream(orc, data, cfg):
+    """With GLOBAL L4 a multi-rank stream selects bases over the global stored-chunk order (batch, rank, local) == the stream
+    order, and dedupes over the same order: cuts, first occurrences, stored chunks, bases, kinds and streams are those of ONE
+    pass of the oracle over the logical stream (pieces are whole segments, so the chunking is the same too)."""
+    oc = orc.default_cfg(**asdict(cfg))
+    cuts = orc.cdc(data, oc)
+    dg = orc.sha256_chunks(data, cuts)
+    fo, rc = orc.dedup(dg)
+    uniq = np.nonzero(fo == np.arange(len(fo), dtype=np.uint64))[0].astype(np.uint64)
+    sig = orc.minhash_chunks(data, cuts, oc, uniq)
+    keys, base = orc.lsh(sig, oc)
+    streams, off, kind = orc.deflate_chunks(data, cuts, oc, uniq, base)
+    return dict(cuts=cuts, digests=dg, first_occ=fo, refcount=rc, uniq=uniq, sig=sig, keys=keys, base=base, streams=streams, off=off, kind=kind)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_l4_stream_stores_the_bytes_of_the_one_rank_run(orc, dev, world):
+    """stream_dist.GlobalL4StreamIngest in lock step on one GPU (BASELINE configs[4] with global L4): every rank's
+    records, put in global stored order, are bit-identical to the oracle's single pass over the logical stream — bases on other
+    ranks (earlier AND later-numbered ones, of earlier batches and of the same batch) included; the in-memory reader and the
+    merged STORE (dictionaries on later-numbered shards: dependency-ordered decode) return the stream."""
+    import torch
+    from hmse_amd import IngestConfig, manifest, read, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset().copy()
+    B = 4 << 20
+    # near-duplicates whose originals sit on a LATER-numbered rank of an earlier batch: batch 2's first piece (rank 0) gets lightly
+    # edited copies of bytes of batch 0's last piece
+    src = data[(2 << 20) + 300000: (2 << 20) + 300000 + 700000].copy()
+    src[::1500] ^= 0x20
+    data[(8 << 20) + 50000: (8 << 20) + 50000 + src.size] = src
+    want = oracle_whole_stream(orc, data, cfg)
+    batches = [torch.from_numpy(data[a: a + B].copy()) for a in range(0, data.size, B)]
+    res = stream_dist.stream_shards_local_global_l4(batches, cfg, world, dev)
+    n_global = len(want["cuts"]) - 1
+    assert all(r.n_global == n_global for r in res)
+    U = len(want["uniq"])
+    assert sorted(np.concatenate([r.ug.cpu().numpy() for r in res]).tolist()) == list(range(U))
+    n_remote = n_later = 0
+    for rank, r in enumerate(res):
+        g = r.gidx.cpu().numpy()
+        c = r.cuts.cpu().numpy().astype(np.int64)
+        gl = np.diff(want["cuts"].astype(np.int64))
+        assert np.array_equal(np.diff(c), gl[g])                                               # this rank's chunks are the stream's
+        assert np.array_equal(r.first_occ.cpu().numpy().astype(np.uint64), want["first_occ"][g])
+        assert np.array_equal(r.refcount.cpu().numpy().astype(want["refcount"].dtype), want["refcount"][g])
+        assert np.array_equal(r.digests.cpu().numpy(), want["digests"][g])
+        ug = r.ug.cpu().numpy()
+        assert np.array_equal(g[r.uniq_ids.cpu().numpy()].astype(np.uint64), want["uniq"][ug])  # stored chunk <-> global stored index
+        assert np.array_equal(r.sig.cpu().numpy().view(np.uint32), want["sig"][ug])
+        assert np.array_equal(r.band_keys.cpu().numpy().view(np.uint32), want["keys"][ug])
+        assert np.array_equal(r.base_global.cpu().numpy(), want["base"][ug].astype(np.int64))
+        assert np.array_equal(r.kind.cpu().numpy(), want["kind"][ug])
+        so, st = r.stream_off.cpu().numpy(), r.streams.cpu().numpy()
+        wo = want["off"].astype(np.int64)
+        for j, u in enumerate(ug):
+            assert np.array_equal(st[so[j]: so[j + 1]], want["streams"][wo[u]: wo[u + 1]]), (rank, j)
+        if r.remote_bases is not None:
+            n_remote += len(r.remote_bases)
+            n_later += int((r.remote_bases["shard"] > rank).sum())
+    assert n_remote > 10 and n_later > 5
+    back = read.reconstruct_shards(res, verify=True)
+    bounds = [stream_dist.deal_batch(b.numel(), world, cfg.seg_size) for b in batches]
+    for r in range(world):
+        mine = np.concatenate([b.numpy()[bd[r]: bd[r + 1]] for b, bd in zip(batches, bounds)])
+        assert np.array_equal(back[r].cpu().numpy(), mine), r
+    sr = stream_dist.store_results(res)
+    parts = [manifest.Manifest.from_bytes(manifest.build_manifest(sr[r], r, world).to_bytes()) for r in range(world)]
+    assert sum(p.n_remote() for p in parts) == n_remote
+    store = manifest.Store.from_bytes(manifest.merge_manifests(parts).to_bytes())
+    assert manifest.reconstruct(store) == data.tobytes()
+    assert np.array_equal(read.read_store(store, dev).cpu().numpy(), data)
+    rd = read.StoreReader(store, dev)
+    rng = np.random.default_rng(11)
+    off = rng.integers(0, data.size - 40000, 150); ln = rng.integers(1, 40000, 150)
+    for o, n, gt in zip(off, ln, rd.read_ranges(list(zip(off.tolist(), ln.tolist())))):
+        assert np.array_equal(gt.cpu().numpy(), data[o: o + n]), (o, n)
+
+
+def _gloo_rank_global_l4(rank, world, port, pieces, cfg_kw, piece_bytes, out_q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from hmse_amd import IngestConfig, stream_dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    cfg = IngestConfig(**cfg_kw)
+    s = stream_dist.GlobalL4StreamIngest(cfg, max(sum(p.size for p in pieces[rank]), 1), piece_bytes, dev, world, rank)
+    for p in pieces[rank]:
+        s.push(torch.from_numpy(p))
+    res = s.finish()
+    out_q.put((rank, {nm: getattr(res, nm).cpu().numpy() for nm in ("ug", "gidx", "base_global", "kind", "stream_off", "streams")}, s.remote_dictionaries))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_l4_stream_two_processes_over_gloo_equal_the_emulation(dev):
+    """The product loop (push -> stage_hash -> all-gather digests -> stage_index -> all-gather signatures -> stage_lsh -> three
+    all-to-alls for the remote dictionaries -> stage_encode) between two REAL processes sharing this GPU (gloo): equals lock step."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from hmse_amd import IngestConfig, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    B, world = 4 << 20, 2
+    batches = [torch.from_numpy(data[a: a + B].copy()) for a in range(0, data.size, B)]
+    want = stream_dist.stream_shards_local_global_l4(batches, cfg, world, dev)
+    names = ("ug", "gidx", "base_global", "kind", "stream_off", "streams")
+    want = [{nm: getattr(r, nm).cpu().numpy() for nm in names} for r in want]
+    pieces = [[], []]
+    for b in batches:
+        bd = stream_dist.deal_batch(b.numel(), world, cfg.seg_size)
+        for r in range(world):
+            pieces[r].append(b[bd[r]: bd[r + 1]].numpy().copy())
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rank_global_l4, args=(r, world, port, pieces, asdict(cfg), 2 << 20, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, arrs, n_remote in got:
+        for nm in names:
+            assert np.array_equal(arrs[nm], want[rank][nm]), (rank, nm)
+    assert sum(g[2] for g in got) > 5
