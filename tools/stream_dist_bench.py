@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--profiles", default="wikipedia,arxiv,news,code")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--verify", action="store_true", help="decode this rank's stored records and re-check their SHA-256 (outside the clock)")
+    ap.add_argument("--global-l4", action="store_true", help="base selection over all ranks (stream_dist.GlobalL4StreamIngest: signatures all-gathered "
+                    "per batch, remote dictionaries fetched by all-to-alls; enqueued stage by stage, no hipGraph); needs --gpus > 1")
     a = ap.parse_args()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -41,6 +43,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.global_l4 and world < 2:
+        raise SystemExit("--global-l4 is a multi-rank mode (one rank: the default stream already selects bases over everything)")
     rehearse = os.environ.get("HMSE_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -75,12 +79,14 @@ def main():
     # warm-up outside the clock: module load, kernel attributes, allocator, the collective's first call
     wp = min(64 << 20, piece)
     wn = max(1, min(4, host.numel() // wp))
-    w = stream_dist.DistStreamIngest(cfg, wn * wp, wp, dev, world, rank, graph=not a.no_graph)
+    mk = (lambda cap, pc: stream_dist.GlobalL4StreamIngest(cfg, cap, pc, dev, world, rank)) if a.global_l4 else \
+        (lambda cap, pc: stream_dist.DistStreamIngest(cfg, cap, pc, dev, world, rank, graph=not a.no_graph))
+    w = mk(wn * wp, wp)
     for k in range(wn):
         w.push(host[k * wp: (k + 1) * wp])
     w.finish(); del w
     barrier()
-    s = stream_dist.DistStreamIngest(cfg, n_batches * piece, piece, dev, world, rank, graph=not a.no_graph)
+    s = mk(n_batches * piece, piece)
     barrier()
     t0 = time.perf_counter()
     for b in range(n_batches):
@@ -93,7 +99,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = res.stats
-    verified = read.verify_stored(res) if a.verify else None
+    verified = read.verify_stored(res) if a.verify and not a.global_l4 else None    # (global L4: dictionaries on other ranks — tests/ decode all ranks together)
     stats = [st]
     if world > 1:
         stats = [None] * world
@@ -103,14 +109,17 @@ def main():
         out = {"metric": "stream_ingest_GiB_per_s", "value": round(total / dt / 2**30, 3), "unit": "GiB/s", "n_gpus": world, "higher_is_better": True,
                "scaling": "strong", "dtype": "u8", "data": "synthetic: wiki-synth profiles " + ",".join(profiles),
                "config": {"workload": f"{total / 1e9:.2f} GB mixed corpora streamed in {n_batches} global batches of {world} x {piece >> 20} MiB pieces, full L1-L4, "
-                                      f"{'hipGraph-captured' if not a.no_graph else 'eagerly enqueued'} per-batch chain, host->HBM copies included",
-                          "collective": "all_gather(exchange rows) per batch over " + ("gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else "RCCL") if world > 1 else "none",
-                          "global_chunk_order": "(batch, rank, local)", "l4_scope": "rank-local"},
+                                      f"{'hipGraph-captured' if not (a.no_graph or a.global_l4) else 'eagerly enqueued'} per-batch chain, host->HBM copies included",
+                          "collective": ("all_gather(digests) + all_gather(signatures) + 3 all_to_all (remote dictionaries) per batch over " if a.global_l4 else "all_gather(exchange rows) per batch over ") + ("gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else "RCCL") if world > 1 else "none",
+                          "global_chunk_order": "(batch, rank, local)", "l4_scope": "global" if a.global_l4 else "rank-local"},
                "ms_total": round(dt * 1e3, 1), "ms_per_batch": round(dt * 1e3 / n_batches, 2), "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4),
                "chunks": tot["chunks"], "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4), "delta_rate": round(tot["delta_rate"], 4),
                "n_global_chunks": res.n_global, "corpus_gen_s": round(t_gen, 1), "hbm_in_use_GiB_rank0": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
         if verified is not None:
             out["sha256_verified_records_rank0"] = verified
+        if a.global_l4:
+            out["remote_dictionaries_rank0"] = s.remote_dictionaries
+            out["ghost_bytes_fetched_rank0"] = s.ghost_bytes_fetched
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
