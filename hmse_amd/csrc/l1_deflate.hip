@@ -123,6 +123,7 @@ struct Small {
   uint32_t red[NT / 64 + 1];
   uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
   uint32_t job, qhead;
+  struct { uint32_t ji, job, L, Dl; uint64_t c, cstart, rec_at, dstart; } nx;   // the NEXT job's metadata, fetched while this one runs
   uint32_t pexit[NT / 64], pexit2[NT / 64], pconv[NT / 64];
   uint8_t wtab[NT];   // dictionary jobs: per wavefront, lane that holds the r-th pending work rank of the wave's window
 };
@@ -417,39 +418,84 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
   unsigned long long stamp_acc[24] = {0}, stamp_last = clock64();
 #endif
 
+  // the whole chain at once (thread 0; the first job of a workgroup, and behind a job that was refused)
+  auto pf_fetch_sync = [&]() {
+    const uint32_t ji2 = atomicAdd(a.counter, 1u);
+    sm.nx.ji = ji2;
+    if (ji2 >= n_jobs) return;
+    const uint32_t job2 = a.jobs[ji2];
+    const uint64_t k2 = job2 >> 1;
+    const uint64_t c2 = a.chunk_ids ? a.chunk_ids[k2] : k2;
+    const uint64_t cs = a.cuts[c2];
+    sm.nx.job = job2; sm.nx.c = c2; sm.nx.cstart = cs; sm.nx.L = (uint32_t)(a.cuts[c2 + 1] - cs); sm.nx.rec_at = a.rec_off[k2];
+    if constexpr (DICT) {
+      const int64_t bsel = a.base[k2];
+      const uint64_t bc = (a.chunk_ids && !a.base_is_chunk) ? a.chunk_ids[bsel] : (uint64_t)bsel;
+      uint64_t ds = a.cuts[bc], dl = a.cuts[bc + 1] - ds;
+      if (dl > WMAX) { ds += dl - WMAX; dl = WMAX; }
+      sm.nx.dstart = ds; sm.nx.Dl = (uint32_t)dl;
+    }
+  };
+  if (threadIdx.x == 0) pf_fetch_sync();
   for (;;) {
     // (the thread index re-read behind a compiler barrier per job: nothing derived from it is hoisted out of this persistent
     // loop and kept in registers across the matcher — see the encode kernel)
     uint32_t t = threadIdx.x;
     asm volatile("" : "+v"(t));
     const uint32_t lane = t & 63u, wave = t >> 6;
+    // The job's metadata (list entry -> chunk id -> cuts -> dictionary chunk -> its cuts; record offset) is a chain of five to seven
+    // dependent global loads: 2-8 % of a job when it is walked at the job's start.  Thread 0 walks the NEXT job's chain one link per
+    // phase of THIS job (PF_STAGE below: a link is issued at one phase boundary and consumed at the next, long after it has
+    // arrived) and leaves the result in sm.nx; a job starts by reading sm.nx.
     __syncthreads();
-    if (t == 0) sm.job = atomicAdd(a.counter, 1u);
-    __syncthreads();
-    const uint32_t ji = uni32(sm.job);   // wave-uniform, and said so: the job's metadata chain (list entry, chunk id, cuts, record offset) becomes scalar loads,
-                                         // lengths and loop bounds live in SGPRs
+    const uint32_t ji = uni32(sm.nx.ji);   // wave-uniform, and said so: lengths and loop bounds live in SGPRs
     if (ji >= n_jobs) break;
     STAMP(10);
-    const uint32_t job = uni32(a.jobs[ji]);
+    const uint32_t job = uni32(sm.nx.job);
     const uint64_t k = job >> 1;
     constexpr uint32_t variant = DICT ? 1u : 0u;  // (== job & 1: the lists are split by variant)
-    const uint64_t c = a.chunk_ids ? uni64(a.chunk_ids[k]) : k;
-    const uint64_t cstart = uni64(a.cuts[c]);
-    const uint32_t L = uni32((uint32_t)(a.cuts[c + 1] - cstart));
-    uint32_t Dl = 0; uint64_t dstart = 0;
-    if (variant == 1) {
-      const int64_t bsel = (int64_t)uni64((uint64_t)a.base[k]);
-      const uint64_t bc = (a.chunk_ids && !a.base_is_chunk) ? uni64(a.chunk_ids[bsel]) : (uint64_t)bsel;
-      dstart = uni64(a.cuts[bc]);
-      uint64_t dl64 = uni64(a.cuts[bc + 1]) - dstart;
-      if (dl64 > WMAX) { dstart += dl64 - WMAX; dl64 = WMAX; }
-      Dl = (uint32_t)dl64;
-    }
+    const uint64_t c = uni64(sm.nx.c);
+    const uint64_t cstart = uni64(sm.nx.cstart);
+    const uint32_t L = uni32(sm.nx.L);
+    const uint32_t Dl = variant ? uni32(sm.nx.Dl) : 0u;
+    const uint64_t dstart = variant ? uni64(sm.nx.dstart) : 0ull;
+    (void)c;
     uint32_t* len_out = variant ? a.len_delta : a.len_full;
     const uint32_t T = Dl + L;
+    // links of the next job's chain in flight (thread 0): issued at one PF_STAGE, consumed at the next; nothing is in flight
+    // across the matcher's state machine (its registers are the kernel's peak)
+    uint32_t pf_u = 0; uint64_t pf_a = 0, pf_b = 0, pf_c = 0;
+    auto pf_stage = [&](int stg) {
+      const bool valid = stg <= 1 || sm.nx.ji < n_jobs;
+      switch (stg) {
+        case 0: pf_u = atomicAdd(a.counter, 1u); break;
+        case 1: sm.nx.ji = pf_u; pf_u = pf_u < n_jobs ? a.jobs[pf_u] : 0u; break;
+        case 2: {
+          sm.nx.job = pf_u;
+          if (valid) { const uint64_t k2 = pf_u >> 1; pf_a = a.chunk_ids ? a.chunk_ids[k2] : k2; pf_b = a.rec_off[k2]; if (DICT) pf_c = (uint64_t)a.base[k2]; }
+          break;
+        }
+        case 3: sm.nx.c = pf_a; sm.nx.rec_at = pf_b; if (DICT) sm.nx.dstart = pf_c; break;   // (dstart: the base index, until stage 6)
+        case 4:
+          if (valid) {
+            const uint64_t c2 = sm.nx.c;
+            pf_a = a.cuts[c2]; pf_b = a.cuts[c2 + 1];
+            if (DICT) { const uint64_t bsel = sm.nx.dstart; pf_c = (a.chunk_ids && !a.base_is_chunk) ? a.chunk_ids[bsel] : bsel; }
+          }
+          break;
+        case 5:
+          sm.nx.cstart = pf_a; sm.nx.L = (uint32_t)(pf_b - pf_a);
+          if (DICT && valid) { const uint64_t bc = pf_c; pf_a = a.cuts[bc]; pf_b = a.cuts[bc + 1]; }
+          break;
+        default:
+          if (DICT && valid) { uint64_t ds = pf_a, dl = pf_b - pf_a; if (dl > WMAX) { ds += dl - WMAX; dl = WMAX; } sm.nx.dstart = ds; sm.nx.Dl = (uint32_t)dl; }
+          break;
+      }
+    };
+#define PF_STAGE(n) do { if (t == 0) pf_stage(n); } while (0)
     // job record: histograms and the token list go to the encode kernel through it.  Classes S2/SG/B keep the match
     // distances (S2) or lengths and distances (SG, B) in a per-workgroup global array while matching.
-    const uint64_t rec_at = uni64(a.rec_off[k]);
+    const uint64_t rec_at = uni64(sm.nx.rec_at);
     uint8_t* const rec = a.recs + rec_at;
     uint16_t* const mdist = (LDSM && !MDG) ? (uint16_t*)(smem + LY::MD_OFF) : mdist_g;
     uint8_t* const mlen = (LDSM && !MLG) ? (uint8_t*)(smem + LY::ML_OFF) : (uint8_t*)(mdist_g + LCAP);
@@ -457,6 +503,8 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     // base is produced by a plain job in a second pass, and only when the delta turns out larger than a fifth of the chunk.
     if (L > (uint32_t)LCAP || T > (uint32_t)TCAP || rec_at + (uint64_t)rec_size(L, variant != 0) > a.rec_cap) {
       if (t == 0) { len_out[k] = 0xFFFFFFFFu; if (L <= 32768u) atomicOr(a.status, 2u); }  // record area too small
+      __syncthreads();                 // everybody has read sm.nx
+      if (t == 0) pf_fetch_sync();     // (no phases to hide the chain behind)
       continue;
     }
     const uint8_t* csrc = a.data + cstart;
@@ -482,6 +530,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     __syncthreads();
 
     STAMP(0);
+    PF_STAGE(0);
     // ---- phase 1-2: bucket histogram + exclusive scan -> bucket starts --------------------------
     const uint32_t nh = T >= 4 ? T - 3 : 0;
     for (uint32_t q = t; q < nh; q += NT) cur_inc(cur, hash4(ld32(W + q)));
@@ -507,6 +556,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     }
     __syncthreads();
     STAMP(1);
+    PF_STAGE(1);
     // ---- phase 3-4: scatter, then rank inside the bucket -> ascending positions -------------------
     {
       // Counting sort with ORDERED buckets, in place.  Positions are scattered NT at a time in ascending
@@ -543,6 +593,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       __syncthreads();  // cursor h now = end of bucket h
     }
     STAMP(2);
+    PF_STAGE(2);
     // ---- phase 4b (dictionary jobs): diagonal anchors ------------------------------------------------
     // A chunk with an LSH base is a near-duplicate of it: most positions have a 258-byte match in the dictionary on the
     // same diagonal as their neighbours, and comparing those bytes again at every position is most of a dictionary job's
@@ -643,6 +694,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // (no barrier needed: the state machine never touches a hinted position's slots, and the parse starts behind a barrier)
     }
     STAMP(6);
+    PF_STAGE(3);
     {
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
       constexpr uint32_t FETCH_BATCH = 16;
@@ -833,6 +885,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     __syncthreads();
     for (uint32_t i = t; i < (L >> 5) + 2; i += NT) mark[i] = 0;   // (held the diagonal anchors of a dictionary job until here)
     STAMP(3);
+    PF_STAGE(4);
     const uint8_t* mlen_c = mlen;
     // Match lengths that live in HBM (the classes that keep them out of LDS) are staged into a free LDS region first: the
     // parse reads each of them three times.
@@ -864,6 +917,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     }
     __syncthreads();
     STAMP(11);
+    PF_STAGE(5);
     // The parse chain 0 -> next(0) -> ... is serial, but LZ parses re-synchronise: chains started at
     // different positions usually merge after a few tokens.  So every wavefront walks its own segment
     // speculatively from the segment start (64 positions per step: the window's `next` values sit in one
@@ -969,6 +1023,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     }
     __syncthreads();
     STAMP(4);
+    PF_STAGE(6);
     // ---- phase 7: tokens in parse order + symbol histograms ------------------------------------------------
     // token index of a marked position = number of marked positions before it: workgroup prefix scan over the
     // popcounts of contiguous mark words, then every thread walks the set bits of its own words
@@ -1018,6 +1073,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     if (t == 0) { stamp_acc[14] += L; stamp_acc[15]++; }
 #endif
   }
+#undef PF_STAGE
 #ifdef HMSE_DFL_STAMPS
   if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
 #endif
