@@ -524,6 +524,11 @@ class GlobalL4StreamIngest:
         from .ingest import fetch_chunks_routed, gather_rows
         torch.cuda.current_stream().wait_event(copied)
         dg = self.stage_hash(off, n)
+        if self.world == 1:       # one rank: no process group needed, every dictionary is local
+            sig = self.stage_index(dg, [int(dg.shape[0])])
+            self.stage_lsh(sig, [int(sig.shape[0])])
+            self.stage_encode(torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.int64, device=self.dev))
+            return
         alld, _, _, bases = gather_rows(dg, self.group)
         counts = [b - a for a, b in zip(bases, list(bases[1:]) + [alld.shape[0]])]
         sig = self.stage_index(alld, counts)

@@ -453,3 +453,19 @@ def test_global_l4_stream_two_processes_over_gloo_equal_the_emulation(dev):
         for nm in names:
             assert np.array_equal(arrs[nm], want[rank][nm]), (rank, nm)
     assert sum(g[2] for g in got) > 5
+
+
+def test_global_l4_stream_on_one_rank_is_the_one_shot_ingest(dev):
+    """GlobalL4StreamIngest at world size 1 (no process group): push/finish like the other front ends, equal to one ingest."""
+    import torch
+    from hmse_amd import IngestConfig, ingest, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()[: 9 << 20]
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    s = stream_dist.GlobalL4StreamIngest(cfg, data.size, 2 << 20, dev, 1, 0)
+    for a in range(0, data.size, 2 << 20):
+        s.push(torch.from_numpy(data[a: a + (2 << 20)].copy()))
+    res = s.finish()
+    for name in NAMES:
+        assert torch.equal(getattr(res, name), getattr(whole, name)), name
+    assert torch.equal(res.base_global, whole.base) and res.remote_bases is None and s.remote_dictionaries == 0
