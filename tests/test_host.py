@@ -314,3 +314,21 @@ def test_document_aligned_segments_and_shards():
         assert sum(sizes) == data.size and max(sizes) - min(sizes) <= 2 * seg
     lo, hi, rel = partition.shard_seg_off(so, *partition.deal_segments(so, 2)[1])
     assert rel[0] == 0 and int(rel[-1]) == hi - lo and hi == data.size
+
+
+def test_dependency_order_of_a_store_whose_dictionaries_sit_on_later_shards():
+    """read.dependency_order: records keep their order when every dictionary precedes its dependants; otherwise they are sorted by
+    dictionary depth (stable) — the store of a multi-rank stream ingested with global L4 (a dictionary on a later-numbered shard)."""
+    from hmse_amd import read
+    assert read.dependency_order(np.array([-1, 0, 1, -1, 3], np.int64)) is None
+    assert read.dependency_order(np.zeros(0, np.int64)) is None
+    base = np.array([4, -1, 0, -1, 3, 2, 1], np.int64)          # 0 <- 4 <- 3 ; 2 <- 0 ; 5 <- 2 ; 6 <- 1
+    order, new_of_old = read.dependency_order(base)
+    assert sorted(order.tolist()) == list(range(7)) and np.array_equal(new_of_old[order], np.arange(7))
+    nb = np.where(base >= 0, new_of_old[np.maximum(base, 0)], -1)[order]
+    assert (nb < np.arange(7)).all()                              # every dictionary now precedes its dependants
+    depth = {1: 0, 3: 0, 4: 1, 6: 1, 0: 2, 2: 3, 5: 4}
+    assert [depth[int(o)] for o in order] == sorted(depth.values())   # by depth, original order inside a depth
+    assert order.tolist() == [1, 3, 4, 6, 0, 2, 5]
+    with pytest.raises(read.ReadError):
+        read.dependency_order(np.array([1, 0], np.int64))         # a cycle
