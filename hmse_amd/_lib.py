@@ -95,6 +95,8 @@ def hip_lib():
         L.hmse_read_assemble.argtypes = [_VP, _U64, _VP, _U64, _VP, _VP, _VP, _U64, _VP, _VP]
         L.hmse_stream_batch_workspace_bytes.restype = _U64
         L.hmse_stream_batch_workspace_bytes.argtypes = [_U64, cfgp]
+        L.hmse_stream_workspace_init.restype = C.c_int
+        L.hmse_stream_workspace_init.argtypes = [_VP, _SZ, _U64, cfgp, _VP]
         L.hmse_stream_batch.restype = C.c_int
         L.hmse_stream_batch.argtypes = [_VP, _U64, _U64, _VP, _U32, cfgp, _VP, _VP, _U64, _VP, _VP, _VP, _VP, _U64, _VP, _U64, _VP, _VP, _VP, _VP,
                                         _U64, _VP, _VP, _VP, _U64, _VP, _SZ, _VP]
@@ -136,4 +138,4 @@ EXPORTED_SYMBOLS = (
     "hmse_cfg_default", "hmse_cfg_validate", "hmse_abi_version", "hmse_strerror", "hmse_gear_table",
     "hmse_workspace_bytes", "hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l3_index_slots", "hmse_l3_index_update",
     "hmse_l4_lsh_slots", "hmse_l4_lsh_update", "hmse_l4_minhash",
-    "hmse_l4_lsh", "hmse_l1_deflate", "hmse_l1_deflate_ex", "hmse_l1_deflate_record_bytes", "hmse_l1_deflate_record_bytes_dict", "hmse_l1_inflate", "hmse_l1_inflate_mode", "hmse_read_assemble", "hmse_manifest_pack", "hmse_manifest_pack_ex", "hmse_stream_batch", "hmse_stream_batch_workspace_bytes", "hmse_stream_row_bytes", "hmse_stream_piece_hash", "hmse_stream_piece_encode", "hmse_profile_enable", "hmse_profile_read", "hmse_profile_counter")
+    "hmse_l4_lsh", "hmse_l1_deflate", "hmse_l1_deflate_ex", "hmse_l1_deflate_record_bytes", "hmse_l1_deflate_record_bytes_dict", "hmse_l1_inflate", "hmse_l1_inflate_mode", "hmse_read_assemble", "hmse_manifest_pack", "hmse_manifest_pack_ex", "hmse_stream_batch", "hmse_stream_batch_workspace_bytes", "hmse_stream_workspace_init", "hmse_stream_row_bytes", "hmse_stream_piece_hash", "hmse_stream_piece_encode", "hmse_profile_enable", "hmse_profile_read", "hmse_profile_counter")

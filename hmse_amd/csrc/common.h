@@ -147,6 +147,7 @@ int hmse_l3_sha256_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts
 // rng: DEVICE u64[2] = {first index, count} of the digests that join the table (state + SB_N_OLD, or state + SB_G_OLD)
 int hmse_l3_index_update_dyn(const uint8_t* digests_all, uint64_t* first_occ, uint32_t* refcount, uint32_t* table, uint64_t slots,
                              const uint64_t* rng, uint64_t cap_chunks, hipStream_t stream);
+int hmse_l4_minhash_memo_init(void* ws, size_t ws_bytes, const hmse_cfg* cfg, hipStream_t stream);
 int hmse_l4_minhash_dyn(const uint8_t* data, uint64_t n_cap, const uint64_t* cuts_all, const uint64_t* uniq_all, uint32_t* sig_all,
                         const uint64_t* st, uint64_t cap_chunks, const hmse_cfg* cfg, void* ws, size_t ws_bytes, hipStream_t stream);
 int hmse_l4_lsh_update_dyn(const uint32_t* sig_all, uint32_t* band_keys, int64_t* base_all, uint32_t* tables, uint64_t slots,

@@ -194,6 +194,13 @@ extern "C" uint64_t hmse_stream_batch_workspace_bytes(uint64_t cap_bytes, const 
   return sb_carve(nullptr, cap_bytes, cfg).total;
 }
 
+extern "C" int hmse_stream_workspace_init(void* ws, size_t ws_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, void* stream) {
+  if (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0 || !ws) return HMSE_EINVAL;
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (ws_bytes < w.total) return HMSE_ENOSPC;
+  return hmse_l4_minhash_memo_init(w.mh_ws, w.mh_bytes, cfg, (hipStream_t)stream);
+}
+
 extern "C" uint64_t hmse_stream_row_bytes(uint64_t cap_bytes, const hmse_cfg* cfg) {
   if (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0) return 0;
   return sb::ROW_HDR + 32 * sb_cap_chunks(cap_bytes, cfg);

@@ -377,6 +377,15 @@ def stream_batch_workspace_bytes(batch_bytes: int, cfg: IngestConfig) -> int:
     return int(_lib.hip_lib().hmse_stream_batch_workspace_bytes(int(batch_bytes), C.byref(c)))
 
 
+def stream_workspace(batch_bytes: int, cfg: IngestConfig, device) -> torch.Tensor:
+    """A workspace for hmse_stream_batch / hmse_stream_piece_*: allocated and prepared once (hmse_stream_workspace_init: the MinHash
+    memo table inside persists across the stream's batches), then passed to every batch."""
+    ws = torch.empty(stream_batch_workspace_bytes(batch_bytes, cfg), dtype=torch.uint8, device=device)
+    c = cfg.to_c()
+    _check(_lib.hip_lib().hmse_stream_workspace_init(ws.data_ptr(), ws.numel(), int(batch_bytes), C.byref(c), _stream()), "hmse_stream_workspace_init")
+    return ws
+
+
 def stream_batch(data: torch.Tensor, batch_bytes: int, seg_off: torch.Tensor, cfg: IngestConfig, state: torch.Tensor, cuts_all: torch.Tensor,
                  max_chunks: int, digests_all: torch.Tensor, first_occ: torch.Tensor, refcount: torch.Tensor, l3_table: torch.Tensor,
                  uniq_all: torch.Tensor, max_unique: int, sig_all: torch.Tensor, band_keys: torch.Tensor, base_all: torch.Tensor,

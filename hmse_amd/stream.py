@@ -191,7 +191,7 @@ class StreamIngest:
         """The ONE host read of the chain: counts after the batches enqueued so far."""
         st = self._state.tolist()
         if st[7]:
-            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 exchange row, "
+            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 exchange row, bit4 workspace not initialised, "
                              "bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped "
                              f"({st[0]} bytes / {st[1]} chunks are intact)")
         self.n_done, self.n_chunks, self.n_unique, self.stream_bytes = st[0], st[1], st[3], st[5]
@@ -214,7 +214,7 @@ class StreamIngest:
         entry = self._graphs.get(n, 0)
         if entry == 0:          # first batch of this size: plain enqueue (also sets the kernels' attributes before any capture)
             seg_off = ops.segment_offsets(n, self.cfg.seg_size, dev)
-            ws = torch.empty(ops.stream_batch_workspace_bytes(n, self.cfg), dtype=torch.uint8, device=dev)
+            ws = ops.stream_workspace(n, self.cfg, dev)
             self._chain_call(n, seg_off, ws)
             self._graphs[n] = (None, ws, seg_off)
         else:

@@ -101,7 +101,7 @@ class DistStreamIngest:
         ops.l3_index_update(self._digests_g, 0, 0, self._first_occ_g, self._refcount_g, self._l3_table)     # clears the table
         ops.l4_lsh_update(self._sig, 0, 0, cfg, self._band_keys, self._base, self._lsh_tables)               # clears the tables
         self._state = torch.zeros(16, dtype=torch.int64, device=device)
-        self._ws = torch.empty(ops.stream_batch_workspace_bytes(self.cap_bytes, cfg), dtype=torch.uint8, device=device)
+        self._ws = ops.stream_workspace(self.cap_bytes, cfg, device)
         self.row_bytes = ops.stream_row_bytes(self.cap_bytes, cfg)
         self._row = torch.zeros(self.row_bytes, dtype=torch.uint8, device=device)
         self._rows = torch.zeros(self.world * self.row_bytes, dtype=torch.uint8, device=device)

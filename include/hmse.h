@@ -275,16 +275,20 @@ int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* 
  * stage takes its ranges from `state` (DEVICE u64[16]: [0] byte offset, [1] chunks so far, [2] chunks of this batch (out),
  * [3] stored chunks so far, [4] stored chunks of this batch (out), [5] stream bytes so far, [6] stream bytes of this batch
  * (out), [7] sticky status: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2 status, bit3 malformed exchange row,
- * bits 8.. DEFLATE status; [8] chunks of ALL ranks so far (== [1] for one rank), [9] chunks of all ranks in this batch (out),
+ * bit4 workspace not initialised (hmse_stream_workspace_init), bits 8.. DEFLATE status; [8] chunks of ALL ranks so far (== [1] for one rank), [9] chunks of all ranks in this batch (out),
  * [10] global index of this rank's first chunk of the batch (out)), grids and workspace are sized for batch_bytes / min_size
  * chunks, and the call ends by advancing [0], [1], [3], [5], [8] — so the chain can be captured into a hipGraph once per batch
  * size and replayed for every batch.  Once [7] is non-zero the failing batch has been dropped and every later call is a no-op
  * (counters frozen at the last good batch): nothing is ever appended to an index that is no longer consistent.  Appends to the
  * per-chunk arrays of the stream (cuts_all, digests_all, first_occ, refcount, uniq_all, sig_all, band_keys, base_all, kind_all,
  * stream_off_all), to the persistent L3 table / L4 band tables, and writes the batch's DEFLATE streams to out[state[5] ..).
- * seg_off DEVICE u64[n_seg+1]: batch-local segment offsets.  ws: hmse_stream_batch_workspace_bytes(batch_bytes, cfg).
+ * seg_off DEVICE u64[n_seg+1]: batch-local segment offsets.  ws: hmse_stream_batch_workspace_bytes(batch_bytes, cfg), prepared ONCE
+ * with hmse_stream_workspace_init() and then handed to every batch of the stream unchanged: it holds the MinHash memo table, which
+ * persists across the batches (a cache of a pure function of (shingle, cfg->seed_base); cleared per batch it cost every 1 GiB batch
+ * its warm-up again).  A chain that finds the workspace untagged drops the batch with status bit4.
  */
 uint64_t hmse_stream_batch_workspace_bytes(uint64_t batch_bytes, const hmse_cfg* cfg);
+int hmse_stream_workspace_init(void* ws, size_t ws_bytes, uint64_t batch_bytes, const hmse_cfg* cfg, void* stream);
 int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batch_bytes, const uint64_t* seg_off, uint32_t n_seg,
                       const hmse_cfg* cfg, uint64_t* state, uint64_t* cuts_all, uint64_t max_chunks, uint8_t* digests_all,
                       uint64_t* first_occ, uint32_t* refcount, uint32_t* l3_table, uint64_t l3_slots, uint64_t* uniq_all,

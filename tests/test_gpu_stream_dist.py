@@ -469,3 +469,20 @@ def test_global_l4_stream_on_one_rank_is_the_one_shot_ingest(dev):
     for name in NAMES:
         assert torch.equal(getattr(res, name), getattr(whole, name)), name
     assert torch.equal(res.base_global, whole.base) and res.remote_bases is None and s.remote_dictionaries == 0
+
+
+def test_chain_refuses_a_workspace_that_was_never_initialised(dev, monkeypatch):
+    """The chain's MinHash memo table persists across batches, so the workspace must be prepared once (hmse_stream_workspace_init,
+    ops.stream_workspace).  A chain handed a raw allocation finds no tag, drops the batch and sets sticky status bit 4 — never
+    signatures computed from garbage table entries."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, ops, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(4 << 20, seed=5)
+    monkeypatch.setattr(ops, "stream_workspace", lambda n, c, d: torch.zeros(ops.stream_batch_workspace_bytes(n, c), dtype=torch.uint8, device=d))
+    s = stream.StreamIngest(cfg, data.size, dev, graph=True)
+    for a in range(0, data.size, 2 << 20):
+        s.push(torch.from_numpy(data[a: a + (2 << 20)].copy()))
+    with pytest.raises(ValueError, match="status 0x10"):
+        s.finish()
+    assert s._state.tolist()[1] == 0 and s._state.tolist()[3] == 0       # nothing was committed
