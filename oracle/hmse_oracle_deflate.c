@@ -295,17 +295,16 @@ static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12
 
 /* ---- encoder --------------------------------------------------------------------------------- */
 
-int64_t orc_deflate(const uint8_t* chunk, uint32_t len, const uint8_t* dict, uint32_t dlen,
-                    const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap) {
-  if (len > 65535u) return HMSE_EINVAL;
-  lz_t z; lz_build(&z, chunk, len, dict, dlen, cfg);
+/* rules 3-6: parse the per-position matches, choose the block type, emit the stream */
+static int64_t encode_matches(const uint8_t* chunk, uint32_t len, const uint16_t* zmlen, const uint16_t* zmdist,
+                              uint8_t* out, uint64_t out_cap) {
   /* parse */
   uint16_t* tl = (uint16_t*)malloc(((size_t)len + 1) * 2); /* literal byte or match length */
   uint16_t* td = (uint16_t*)malloc(((size_t)len + 1) * 2); /* 0 = literal, else distance (65536 never occurs: <= 32768) */
   uint32_t nt = 0;
   for (uint32_t p = 0; p < len;) {
-    uint32_t ml = z.mlen[p];
-    if (ml >= MINM && !(p + 1 < len && z.mlen[p + 1] > ml)) { tl[nt] = (uint16_t)ml; td[nt] = z.mdist[p]; nt++; p += ml; }
+    uint32_t ml = zmlen[p];
+    if (ml >= MINM && !(p + 1 < len && zmlen[p + 1] > ml)) { tl[nt] = (uint16_t)ml; td[nt] = zmdist[p]; nt++; p += ml; }
     else { tl[nt] = chunk[p]; td[nt] = 0; nt++; p++; }
   }
   /* frequencies */
@@ -367,9 +366,18 @@ int64_t orc_deflate(const uint8_t* chunk, uint32_t len, const uint8_t* dict, uin
     bw_put(&b, lc[256], ll[256]);
     bw_flush(&b);
   }
-  free(tl); free(td); lz_free(&z);
+  free(tl); free(td);
   if (b.ovf) return HMSE_ENOSPC;
   return (int64_t)b.pos;
+}
+
+int64_t orc_deflate(const uint8_t* chunk, uint32_t len, const uint8_t* dict, uint32_t dlen,
+                    const hmse_cfg* cfg, uint8_t* out, uint64_t out_cap) {
+  if (len > 65535u) return HMSE_EINVAL;
+  lz_t z; lz_build(&z, chunk, len, dict, dlen, cfg);
+  int64_t n = encode_matches(chunk, len, z.mlen, z.mdist, out, out_cap);
+  lz_free(&z);
+  return n;
 }
 
 /* Batch form (mirrors hmse_l1_deflate), rule 7: with a base the dictionary stream comes first; it is the record
