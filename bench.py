@@ -177,8 +177,44 @@ def valu_issue_note():
 
 
 # ------------------------------------------------------------------------------------------ main
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no RANK / WORLD_SIZE in the environment): start the N ranks
+    here — a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, spawned before this
+    process imports torch or touches a GPU — and relay rank 0's JSON line.  Never a 1-GPU run labelled N."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print(f"[bench] the {a.gpus}-rank run failed (rc {p.returncode}); no result line", file=sys.stderr, flush=True)
+        return p.returncode or 1
+    sys.stdout.write(lines[-1] + "\n"); sys.stdout.flush()
+    return 0
+
+
+def one_gpu_cf_reference(corpus_name: str, total_bytes: int):
+    """CF of the ONE-GPU run of the same corpus and size (north_star: "CF identical"): an N > 1 line reports it beside its own CF,
+    whose shard-local L4 finds fewer bases.  From the committed 1-GPU bench lines (profiles/cf_one_gpu.json)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "cf_one_gpu.json")))
+        e = t[corpus_name][str(total_bytes)]
+        return {"cf": e["cf"], "cf_payload": e.get("cf_payload"), "source": e["source"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner there at its
     # first collective) are sent to stderr for the whole run, and the result is written to the saved descriptor
     sys.stdout.flush()
@@ -191,8 +227,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the result line would name the wrong GPU count")
+    if os.environ.get("HMSE_BENCH_LAUNCH_ONLY") == "1":
+        # launcher check (tests/test_host.py, no GPU): every rank reports in over gloo, rank 0 prints who came
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = [None] * world
+            dist.all_gather_object(seen, (rank, local_rank))
+            dist.destroy_process_group()
+        else:
+            seen = [(rank, local_rank)]
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"launch_check": True, "n_gpus": world, "ranks": sorted(r for r, _ in seen)}) + "\n").encode())
+        return
     cfg = IngestConfig(layers=ABLATIONS[a.layers])
     seg = cfg.seg_size
     total = int(a.bytes) if a.scaling == "strong" else int(a.bytes) * world
@@ -389,6 +437,11 @@ def main():
             "h2d_inclusive_GiB_per_s": round(tot["bytes"] / (dt / a.steps + t_h2d) / 2**30, 3),
             "corpus_gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 2),
         }
+        if world > 1:
+            # the CF claim of north_star ("CF identical to the CPU reference" = the one-GPU run's) made visible: shard-local L4 finds
+            # fewer bases as the shards shrink; --global-l4 restores the one-GPU bytes (tests/test_gpu_ingest.py)
+            out["cf_one_gpu_reference"] = one_gpu_cf_reference(a.corpus, tot["bytes"])
+            out["l4_scope"] = "global (signature all-gather + cross-GPU base fetch)" if a.global_l4 else "shard-local"
         if dom:
             r = stage_roof[dom]
             # stages = groups of kernels: the DEFLATE match kernels run as up to twelve launches (size class x plain/dictionary)

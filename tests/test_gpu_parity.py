@@ -301,6 +301,34 @@ def test_l1_deflate_dictionary_jobs_adversarial(orc, dev):
         assert d.decompress(st) == parts[j].tobytes()
 
 
+@pytest.mark.parametrize("L,n_copies", [(4096, 1600), (10000, 1100)], ids=["class-S", "class-SG2"])
+def test_l1_deflate_more_dictionary_jobs_of_one_class_than_resident_workgroups(L, n_copies, orc, dev):
+    """the round-3 hang of the dictionary matcher's work queue needed MORE dictionary jobs of one size class
+    than the launch has workgroups (grid = min(2 * jobs, 512)): a workgroup then takes a second, third ... dictionary job, the
+    next job's metadata is handed over in LDS (`sm.nx`) and the wavefront queue restarts.  One base chunk, `n_copies` lightly edited
+    copies that all name it as their dictionary — window 2 L: class S (L = 4096) and class SG2 (L = 10000) — streams, offsets and
+    kinds equal the oracle's; ops.l1_deflate raises on any device status bit (bit 4 = the trip budget), so status is 0."""
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    rng = np.random.default_rng(L)
+    base_chunk = words_text(L, seed=L)
+    parts = [base_chunk]
+    for i in range(n_copies):
+        v = base_chunk.copy()
+        k = 1 + i % 7
+        v[rng.integers(0, L, k)] = rng.integers(32, 127, k, dtype=np.uint8)
+        parts.append(v)
+    data = np.concatenate(parts)
+    cuts = (np.arange(len(parts) + 1, dtype=np.uint64) * np.uint64(L))
+    base = np.zeros(len(parts), dtype=np.int64); base[0] = -1
+    want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, ocfg(orc, cfg), None, base)
+    out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg, None, to_dev(base, dev))
+    assert np.array_equal(kind.cpu().numpy(), want_kind)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert np.array_equal(out.cpu().numpy(), want_out)
+    assert (want_kind[1:] == 2).all()
+
+
 def test_l1_deflate_near_incompressible_record_slots(orc, dev):
     """Streams whose size is within a byte of the stored size (L + 4 of L + 5), at 256 consecutive chunk lengths: the
     encode kernel copies its bit image out in whole 16-byte stores, which must not reach the neighbouring job record

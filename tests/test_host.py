@@ -332,3 +332,26 @@ def test_dependency_order_of_a_store_whose_dictionaries_sit_on_later_shards():
     assert order.tolist() == [1, 3, 4, 6, 0, 2, 5]
     with pytest.raises(read.ReadError):
         read.dependency_order(np.array([1, 0], np.int64))         # a cycle
+
+
+def test_bench_started_bare_with_gpus_2_runs_two_ranks_or_fails():
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run must never print an n_gpus-1 line for N GPUs:
+    it starts the N ranks itself (child launcher, before torch is imported) or exits non-zero.  HMSE_BENCH_LAUNCH_ONLY=1 stops
+    every rank after the rendezvous (gloo, no GPU), rank 0 printing who came."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HMSE_BENCH_LAUNCH_ONLY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, timeout=300)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr.decode()[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == [0, 1]
+    # a launcher environment that disagrees with --gpus is refused, whatever the order of magnitude
+    for ws in ("1", "4"):
+        q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0"),
+                           capture_output=True, timeout=120)
+        assert q.returncode != 0 and not [ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")]
