@@ -355,3 +355,44 @@ def test_bench_started_bare_with_gpus_2_runs_two_ranks_or_fails():
         q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0"),
                            capture_output=True, timeout=120)
         assert q.returncode != 0 and not [ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_isa_audit_finds_nothing_unpinned():
+    """a static guard for the hazard that hung the GPU in rounds 1 and 3 (a cross-lane read inside a loop the
+    compiler structurised as divergent).  tools/isa_audit.py disassembles the shipped library (CPU only); every finding must be
+    pinned, with its justification, in tests/golden/isa_audit.json — a new one fails here instead of hanging a GPU box.  Also: the
+    library imports no asynchronous memset / memcpy (a captured chain must hold kernel nodes only)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "hmse_amd", "csrc", "libhmse_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_audit
+    pin = json.load(open(os.path.join(root, "tests", "golden", "isa_audit.json")))
+    rep = isa_audit.audit(lib)
+    assert len(rep) >= 40 and sum(v["loops"] for v in rep.values()) > 300          # the audit saw the kernels and their loops
+    # the regression inputs: the two shapes that hung are recognised when fed back as instruction lists
+    hang = [(0, "s_mov_b64", "s[0:1], 0", None), (4, "ds_bpermute_b32", "v1, v2, v3", None), (8, "s_andn2_b64", "exec, exec, s[0:1]", None),
+            (12, "s_cbranch_execnz", "65533", 4), (16, "s_endpgm", "", None)]
+    f, n_loops, n_div = isa_audit.audit_function(hang)
+    assert n_loops == 1 and n_div == 1 and [x[1] for x in f] == ["ds_bpermute_b32"]
+    scalar = [(0, "s_mov_b32", "s0, 0", None), (4, "ds_bpermute_b32", "v1, v2, v3", None), (8, "s_cmp_lt_u32", "s0, s1", None),
+              (12, "s_cbranch_scc1", "65533", 4), (16, "s_endpgm", "", None)]
+    assert isa_audit.audit_function(scalar)[0] == []                                   # the same read in a scalar loop is fine
+    bad = []
+    for kern, ops in isa_audit.summary(rep).items():
+        fam = [k for k in pin["kernels"] if kern == k or (k.endswith("<") and kern.startswith(k))]
+        if not fam:
+            bad.append((kern, ops, "kernel not pinned"))
+            continue
+        allowed = pin["kernels"][fam[0]]["allowed"]
+        for op, cnt in ops.items():
+            if cnt > allowed.get(op, 0):
+                bad.append((kern, op, cnt, "pinned: %d" % allowed.get(op, 0)))
+    assert not bad, bad
+    imports = isa_audit.imported_hip_calls(lib)
+    assert not [s for s in imports if "Async" in s or "Graph" in s], imports
+    assert set(imports) <= set(pin["hip_imports_allowed"]), sorted(set(imports) - set(pin["hip_imports_allowed"]))
