@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const uint8_t* __restr
     total += c;
   }
   const bool over = g_old + total > max_chunks_g;
-  if (dead || bad || over) total = 0;
+  // one rank: the global chunk order IS the local one, so the two counters must agree (a caller resuming a stream with the
+  // ABI-1 state layout has state[8] = 0 and would overwrite digests from index 0 on) — refused with sticky status bit 5
+  const bool stale = world == 1 && g_old != st[SB_N_OLD];
+  if (dead || bad || over || stale) total = 0;
   if (r < world && total && j < cnt_r) {
     const uint4 v = *(const uint4*)(rows + (size_t)r * row_bytes + ROW_HDR + 32 * j + 16 * half);
     *(uint4*)(digests_g + 32 * (g_old + before + j) + 16 * half) = v;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void ingest_rows_kernel(const uint8_t* __restr
   if (tid == 0) {
     st[SB_G_NEW] = total;
     st[SB_G_BASE] = g_old + mine_before;
-    if (!dead && (bad || over)) { st[SB_STATUS] |= bad ? 8ull : 1ull; st[SB_N_NEW] = 0; }
+    if (!dead && (bad || over || stale)) { st[SB_STATUS] |= stale ? 32ull : bad ? 8ull : 1ull; st[SB_N_NEW] = 0; }
   }
 }
 

@@ -101,6 +101,7 @@ class DistStreamIngest:
         ops.l3_index_update(self._digests_g, 0, 0, self._first_occ_g, self._refcount_g, self._l3_table)     # clears the table
         ops.l4_lsh_update(self._sig, 0, 0, cfg, self._band_keys, self._base, self._lsh_tables)               # clears the tables
         self._state = torch.zeros(16, dtype=torch.int64, device=device)
+        self._host_error = None
         self._ws = ops.stream_workspace(self.cap_bytes, cfg, device)
         self.row_bytes = ops.stream_row_bytes(self.cap_bytes, cfg)
         self._row = torch.zeros(self.row_bytes, dtype=torch.uint8, device=device)
@@ -179,12 +180,21 @@ class DistStreamIngest:
         """Issue the host -> HBM copy of this rank's piece of the next global batch, then process the piece whose copy was
         issued by the previous push (its kernels overlap this copy).  COLLECTIVE: every rank pushes once per global batch."""
         n = host_piece.numel()
+        err = None
         if n > self.cap_bytes:
-            raise ValueError("a piece may not exceed the stream's nominal piece size")
-        if self.n_bytes % self.cfg.seg_size:
-            raise ValueError("only a rank's last piece may end inside a segment")
-        if self.n_bytes + n > self.data.numel():
-            raise ValueError("stream capacity exceeded")
+            err = "a piece may not exceed the stream's nominal piece size"
+        elif self.n_bytes % self.cfg.seg_size:
+            err = "only a rank's last piece may end inside a segment"
+        elif self.n_bytes + n > self.data.numel():
+            err = "stream capacity exceeded"
+        if err:
+            # A rank that raised here alone would leave its peers blocked in this batch's all-gather (ADVICE r3).  Instead the piece
+            # is refused THROUGH the chain: sticky status bit 6 on the device (phase A then reports 0 chunks, every later batch of
+            # this rank is a no-op), the rank keeps taking part in the collectives with empty rows, and read_state()'s
+            # all-reduce(MAX) of the status makes EVERY rank raise at finish() — this one with the reason.
+            self._host_error = self._host_error or err
+            self._state[7:8] |= 64
+            n, host_piece = 0, host_piece[:0]
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
             if n:
@@ -213,7 +223,9 @@ class DistStreamIngest:
             status = max(status, int(t.item()))
         if check and status:
             raise ValueError(f"streaming chain status {status:#x} on some rank: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 "
-                             "exchange row, bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped")
+                             "exchange row, bit4 workspace not initialised, bit5 state block inconsistent, bit6 a piece refused by push()"
+                             + (f" (this rank: {self._host_error})" if self._host_error else "")
+                             + ", bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped")
         return st
 
     def finish(self, check: bool = True) -> ShardResult:
@@ -502,14 +514,41 @@ class GlobalL4StreamIngest:
         self.n_batches += 1
 
     # ------------------------------------------------------------------ N processes: the stages joined by collectives
+    def _agree(self, err) -> None:
+        """COLLECTIVE: did this rank's last step fail?  If ANY rank says yes, EVERY rank raises — a rank that raised alone between two
+        collectives would leave its peers blocked in the next one with no diagnosis.  (This mode is host-sized: it
+        synchronises per stage anyway.)"""
+        if self.world == 1:
+            if err is not None:
+                raise err
+            return
+        import torch.distributed as dist
+        flags = [None] * self.world
+        dist.all_gather_object(flags, None if err is None else str(err), group=self.group)
+        bad = [(r, m) for r, m in enumerate(flags) if m is not None]
+        if bad:
+            self.failed = True
+            raise ValueError("global-L4 stream abandoned on every rank: " + "; ".join(f"rank {r}: {m}" for r, m in bad))
+
+    def _guard(self, fn, *args):
+        """Run one stage; its rank-local refusal (a capacity) is agreed with the peers before anybody meets the next collective."""
+        try:
+            out, err = fn(*args), None
+        except ValueError as e:
+            out, err = None, e
+        self._agree(err)
+        return out
+
     def push(self, host_piece: torch.Tensor) -> None:
         """COLLECTIVE (every rank pushes once per global batch, an empty tensor if it has no bytes in it): issue the host -> HBM
         copy of this piece, then process the piece pushed before."""
         n = host_piece.numel()
+        err = None
         if self.n_bytes % self.cfg.seg_size:
-            raise ValueError("only a rank's last piece may end inside a segment")
-        if self.n_bytes + n > self.capacity:
-            raise ValueError("stream capacity exceeded")
+            err = ValueError("only a rank's last piece may end inside a segment")
+        elif self.n_bytes + n > self.capacity:
+            err = ValueError("stream capacity exceeded")
+        self._agree(err)
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
             if n:
@@ -523,7 +562,7 @@ class GlobalL4StreamIngest:
     def _process(self, off: int, n: int, copied) -> None:
         from .ingest import fetch_chunks_routed, gather_rows
         torch.cuda.current_stream().wait_event(copied)
-        dg = self.stage_hash(off, n)
+        dg = self._guard(self.stage_hash, off, n)
         if self.world == 1:       # one rank: no process group needed, every dictionary is local
             sig = self.stage_index(dg, [int(dg.shape[0])])
             self.stage_lsh(sig, [int(sig.shape[0])])
@@ -531,13 +570,13 @@ class GlobalL4StreamIngest:
             return
         alld, _, _, bases = gather_rows(dg, self.group)
         counts = [b - a for a, b in zip(bases, list(bases[1:]) + [alld.shape[0]])]
-        sig = self.stage_index(alld, counts)
+        sig = self._guard(self.stage_index, alld, counts)
         alls, _, _, ub = gather_rows(sig, self.group)
         counts_u = [b - a for a, b in zip(ub, list(ub[1:]) + [alls.shape[0]])]
-        rc, rl = self.stage_lsh(alls, counts_u)
+        rc, rl = self._guard(self.stage_lsh, alls, counts_u)
         uniq_all = torch.cat(self._uniq + [self._cur["uniq_new"]])
         ghost, glens = fetch_chunks_routed(rc, rl, self.data, self._cuts, uniq_all, self.group)
-        self.stage_encode(ghost, glens)
+        self._guard(self.stage_encode, ghost, glens)
 
     def finish(self) -> ShardResult:
         while self.pending:

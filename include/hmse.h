@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define HMSE_ABI_VERSION 1
+/* 2 (round 4): contracts of existing entry points changed in round 3 — hmse_stream_batch / hmse_stream_piece_* need a workspace
+ * prepared by hmse_stream_workspace_init (else status bit4) and take the global chunk count from state[8] (one rank: state[8] must
+ * equal state[1]; a mismatch is status bit5); hmse_l1_deflate keeps ONE record per chunk in its workspace
+ * (hmse_l1_deflate_record_bytes / _dict).  A caller built against version 1 must check hmse_abi_version() and refuse. */
+#define HMSE_ABI_VERSION 2
 
 enum {
   HMSE_OK      = 0,
@@ -275,7 +279,8 @@ int hmse_read_assemble(const uint64_t* cuts, uint64_t n_chunks, const uint64_t* 
  * stage takes its ranges from `state` (DEVICE u64[16]: [0] byte offset, [1] chunks so far, [2] chunks of this batch (out),
  * [3] stored chunks so far, [4] stored chunks of this batch (out), [5] stream bytes so far, [6] stream bytes of this batch
  * (out), [7] sticky status: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2 status, bit3 malformed exchange row,
- * bit4 workspace not initialised (hmse_stream_workspace_init), bits 8.. DEFLATE status; [8] chunks of ALL ranks so far (== [1] for one rank), [9] chunks of all ranks in this batch (out),
+ * bit4 workspace not initialised (hmse_stream_workspace_init), bit5 state block inconsistent (one rank and [8] != [1]: e.g. a stream resumed with the
+ * version-1 state layout, whose [8] is 0), bits 8.. DEFLATE status; [8] chunks of ALL ranks so far (== [1] for one rank), [9] chunks of all ranks in this batch (out),
  * [10] global index of this rank's first chunk of the batch (out)), grids and workspace are sized for batch_bytes / min_size
  * chunks, and the call ends by advancing [0], [1], [3], [5], [8] — so the chain can be captured into a hipGraph once per batch
  * size and replayed for every batch.  Once [7] is non-zero the failing batch has been dropped and every later call is a no-op

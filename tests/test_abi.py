@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hmse.h but not exported"
     assert set(_lib.EXPORTED_SYMBOLS) == set(names)
-    assert lib.hmse_abi_version() == 1
+    assert lib.hmse_abi_version() == 2
 
 
 def test_library_exports_nothing_but_the_declared_abi():

@@ -184,3 +184,49 @@ def test_stream_row_exchange_and_global_order_two_ranks(orc):
     fo, rc = orc.dedup(glob[0])
     fo1, rc1 = orc.dedup(whole)
     assert np.array_equal(fo, fo1) and np.array_equal(rc, rc1) and (fo != np.arange(len(fo))).sum() > 100
+
+
+def _agree_worker(rank, world, port, q):
+    """Two ranks of a global-L4 stream in which rank 1's stage is refused (a capacity): BOTH must raise, at the same point."""
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from hmse_amd.stream_dist import GlobalL4StreamIngest
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = object.__new__(GlobalL4StreamIngest)          # the agreement logic only: no device state
+    s.world, s.rank, s.group, s.failed = world, rank, None, False
+
+    def stage(ok):
+        if not ok:
+            raise ValueError("stream index capacity exceeded (max_chunks)")
+        return 7
+    out = []
+    out.append(s._guard(stage, True))                 # batch 1: both fine
+    try:
+        s._guard(stage, rank != 1)                    # batch 2: rank 1 is refused
+        out.append("no error")
+    except ValueError as e:
+        out.append(str(e))
+    dist.barrier()                                    # nobody is left behind in a collective: both ranks reach this
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_a_rank_local_refusal_in_a_global_l4_stream_raises_on_every_rank():
+    """GlobalL4StreamIngest's stages raise rank-local host errors (capacities) between collectives; `_guard` / `_agree`
+    exchange an error word first, so that every rank raises the same error instead of one rank leaving and its peers blocking."""
+    import multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r][0] == 7
+        assert "rank 1: stream index capacity exceeded" in got[r][1] and "abandoned on every rank" in got[r][1]

@@ -210,6 +210,50 @@ def test_capacity_overflow_sets_the_sticky_status_and_drops_the_batch(dev, which
             assert torch.equal(s._uniq[s.max_unique:], guard["_uniq"][s.max_unique:])
 
 
+def test_a_one_rank_state_block_whose_global_count_disagrees_is_refused(dev):
+    """ADVICE r3 (include/hmse.h, ABI 2): with one rank the global chunk count state[8] must equal the local one state[1].  A caller
+    that resumes a stream with the version-1 state layout (state[8] = 0) would overwrite digests and first occurrences from index 0
+    on; the chain refuses the batch with sticky status bit 5 and commits nothing."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(4 << 20, seed=6)
+    B = 2 << 20
+    s = stream.StreamIngest(cfg, data.size, dev, graph=True)
+    s.push(torch.from_numpy(data[:B].copy()))
+    torch.cuda.synchronize()
+    st0 = s._state.tolist()
+    assert st0[7] == 0 and st0[8] == st0[1] > 0
+    digests = s._digests[: st0[1]].clone()
+    s._state[8] = 0                                                     # what a version-1 caller's resume would have left there
+    s.push(torch.from_numpy(data[B:].copy()))
+    with pytest.raises(ValueError, match="status"):
+        s.finish()
+    st = s._state.tolist()
+    assert st[7] & 32, hex(st[7])
+    assert st[1] == st0[1] and st[3] == st0[3] and st[5] == st0[5]      # counters frozen at the last good batch
+    assert torch.equal(s._digests[: st0[1]], digests)                   # and nothing was overwritten
+
+
+def test_a_piece_refused_by_push_poisons_the_stream_instead_of_raising_alone(dev):
+    """DistStreamIngest.push() is a collective step; a rank whose piece is refused (here: larger than the nominal piece
+    size) must not raise alone and leave its peers in the batch's all-gather.  The piece is refused through the chain (sticky
+    status bit 6, an empty row), the rank keeps in step, and finish() raises on every rank (the all-reduce of the status)."""
+    import torch
+    from hmse_amd import IngestConfig, corpus, stream_dist
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = corpus.wiki_synth(5 << 20, seed=8)
+    B = 2 << 20
+    s = stream_dist.DistStreamIngest(cfg, 8 << 20, B, dev, 1, 0, graph=True)
+    s.push(torch.from_numpy(data[:B].copy()))
+    s.push(torch.from_numpy(data[B: B + B + (1 << 20)].copy()))           # 3 MiB > the nominal 2 MiB: refused, not raised
+    s.push(torch.from_numpy(data[:B].copy()))                             # later pieces are no-ops
+    with pytest.raises(ValueError, match="refused by push"):
+        s.finish()
+    st = s._state.tolist()
+    assert st[7] & 64 and st[0] == B                                      # the first piece is intact, nothing else was committed
+
+
 def _gloo_rank(rank, world, port, pieces, cfg_kw, piece_bytes, out_q):
     """One rank of a 2-process stream on GPU 0: the product loop (DistStreamIngest.push -> phase A -> all-gather of the rows over
     gloo -> phase B) between real processes."""

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 from oracle import oracle as O
 import lz_study as S
 from multiprocessing import Pool
-V = {"r3: batch 16": (16, 0, 0), "33 classes by chain length": (16, 48, 99 << 8), "8 classes by chain length": (16, 48, 98 << 8), "8 classes + prefetch": (16, 49, 98 << 8), "no extend trips at all": (16 + 256, 0, 0), "extend 64 B per trip": (16 + 512, 0, 0), "no extend trips + perfect LF": (16 + 256, 16, 0), "perfect longest-first": (16, 16, 0), "chains >= 8 first": (16, 32, 8 << 8), "chains >= 16 first": (16, 32, 16 << 8), "chains >= 24 first": (16, 32, 24 << 8), "four classes by chain length": (16, 48, 0),
+V = {"r3: batch 16": (16, 0, 0), "no first-of-bucket ranks in the queue": (16, 48, 95 << 8), "3 classes, no kmax 0": (16, 48, 96 << 8), "4 classes, no kmax 0": (16, 48, 97 << 8), "8 classes, no kmax 0": (16, 48, 98 << 8), "8 classes, no kmax 0, batch 8": (8, 48, 98 << 8), "8 classes, no kmax 0, batch 24": (24, 48, 98 << 8), "33 classes by chain length": (16, 48, 99 << 8), "8 classes by chain length": (16, 48, 98 << 8), "8 classes + prefetch": (16, 49, 98 << 8), "no extend trips at all": (16 + 256, 0, 0), "extend 64 B per trip": (16 + 512, 0, 0), "no extend trips + perfect LF": (16 + 256, 16, 0), "perfect longest-first": (16, 16, 0), "chains >= 8 first": (16, 32, 8 << 8), "chains >= 16 first": (16, 32, 16 << 8), "chains >= 24 first": (16, 32, 24 << 8), "four classes by chain length": (16, 48, 0),
      "buckets >= 8 first, reversed": (16, 64, 8 << 8), "buckets >= 16 first, reversed": (16, 64, 16 << 8), "buckets >= 4 first, reversed": (16, 64, 4 << 8), "four bucket classes, reversed": (16, 80, 0),
      "perfect LF + prefetch slot": (16, 17, 0), "four classes + prefetch": (16, 49, 0), "batch 1": (1, 0, 0), "batch 8": (8, 0, 0), "prefetch slot, batch 16": (16, 1, 0), "prefetch slot, batch 32": (32, 1, 0), "coop tail <= 8": (16, 2, 8), "coop tail <= 16": (16, 2, 16),
      "prefetch + coop tail <= 8": (16, 3, 8), "prefetch + coop tail <= 16": (16, 3, 16)}

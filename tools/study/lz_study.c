@@ -164,6 +164,7 @@ void study_sched(const uint8_t* chunk, uint32_t len, uint32_t D, uint32_t NW, ui
   uint32_t* trips = (uint32_t*)calloc(nh + 1, 4);
   for (uint32_t r = 0; r < nh; r++) { uint64_t o[8] = {0}; walk_trips(&x, x.S[r], D, 0, 2, o); trips[r] = (uint32_t)(o[0] + ((batch >> 8) == 1 ? 0 : (batch >> 8) == 2 ? (o[1] + 1) / 2 : o[1])); }
   batch &= 255;
+  uint32_t nh_drop = 0;
   /* hand-out order: (variant >> 4) 0 = rank order; 1 = perfect longest-first (by modelled trips); 2 = chains >= othr candidates first, then the
      rest (two passes over the ranks); 3 = four classes by chain length (>= 24, >= 16, >= 8, rest) */
   {
@@ -172,10 +173,11 @@ void study_sched(const uint8_t* chunk, uint32_t len, uint32_t D, uint32_t NW, ui
       uint32_t* key = (uint32_t*)calloc(nh + 1, 4); uint32_t* t2 = (uint32_t*)calloc(nh + 1, 4);
       for (uint32_t r = 0; r < nh; r++) {
         uint32_t h = hash4(le32(x.W + x.S[r])), km = r - x.start[h]; if (km > D) km = D;
-        key[r] = om == 1 ? trips[r] : om == 2 ? (km >= othr) : othr == 99 ? km : othr == 98 ? (km >= 32 ? 7 : km >= 24 ? 6 : km >= 16 ? 5 : km >= 12 ? 4 : km >= 8 ? 3 : km >= 4 ? 2 : km >= 2 ? 1 : 0) : (km >= 24 ? 3 : km >= 16 ? 2 : km >= 8 ? 1 : 0);
+        key[r] = om == 1 ? trips[r] : om == 2 ? (km >= othr) : othr == 97 ? (km >= 24 ? 4 : km >= 12 ? 3 : km >= 4 ? 2 : km >= 1 ? 1 : 0) : othr == 96 ? (km >= 16 ? 3 : km >= 4 ? 2 : km >= 1 ? 1 : 0) : othr == 95 ? (km >= 1) : othr == 99 ? km : othr == 98 ? (km >= 32 ? 7 : km >= 24 ? 6 : km >= 16 ? 5 : km >= 12 ? 4 : km >= 8 ? 3 : km >= 4 ? 2 : km >= 2 ? 1 : 0) : (km >= 24 ? 3 : km >= 16 ? 2 : km >= 8 ? 1 : 0);
       }
       uint32_t n = 0;
       for (int k = 1024; k >= 0; k--) for (uint32_t r = 0; r < nh; r++) if (key[r] == (uint32_t)k || (k == 1024 && key[r] > 1024)) t2[n++] = trips[r];
+      if (om == 3 && othr >= 95 && othr <= 98) { uint32_t n0 = 0; for (uint32_t r = 0; r < nh; r++) n0 += key[r] == 0; n -= n0; for (uint32_t r = n; r < nh; r++) t2[r] = 0; nh_drop = n0; }
       memcpy(trips, t2, nh * 4); free(key); free(t2);
     }
     if (om >= 4) {
@@ -198,6 +200,7 @@ void study_sched(const uint8_t* chunk, uint32_t len, uint32_t D, uint32_t NW, ui
     }
     variant &= 15; ctail &= 255;
   }
+  nh -= nh_drop;
   uint32_t qhead = 0;
   typedef struct { uint32_t rem[64]; uint8_t st[64]; uint32_t nxt[64]; uint8_t has[64]; int fin; } wv_t;  /* st: 0 idle, 1 walking, 2 done */
   wv_t* w = (wv_t*)calloc(NW, sizeof(wv_t));
