@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--global-l4", action="store_true",
                     help="N > 1: base selection over all shards (signature all-gather + cross-GPU base fetch) instead of shard-local; "
                          "the stored bytes are then those of the 1-GPU run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the side measurements of BASELINE configs[1] / configs[4] (one rank)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample (0 = 4 MiB x 2 x cores, <= 256 MiB)")
     return ap.parse_args()
 
@@ -174,6 +175,69 @@ def valu_issue_note():
         return json.load(open(os.path.join(ROOT, "profiles", "sq_valu.json")))
     except (OSError, ValueError):
         return None
+
+
+def other_configs(data, host, dev, cfg_full) -> dict:
+    """BASELINE.json configs[1] and the one-rank form of configs[4], measured in the driver's own run AFTER the headline's timed region
+    (both existed only as builder-run files).  Outside `value`; reported under "other_configs"."""
+    import torch
+    from hmse_amd import ABLATIONS, IngestConfig, corpus, ingest, ops, stream
+    out = {}
+    seg = cfg_full.seg_size
+    # configs[1]: FastCDC (8 KiB avg) + SHA-256 dedup on 1 GB, cut points / digests bit-exact vs the CPU (tests/test_gpu_parity.py)
+    n1 = min(int(1e9), data.numel()) // seg * seg
+    cfg1 = IngestConfig(layers=ABLATIONS["cdc_dedupe"])
+    d1 = data[:n1]
+    so1 = ops.segment_offsets(n1, seg, dev)
+    r1 = None
+    for _ in range(3):
+        r1 = ingest.ingest_shard(d1, cfg1, so1, want_stats=False)
+    torch.cuda.synchronize()
+    steps1 = 20
+    t0 = time.perf_counter()
+    for _ in range(steps1):
+        r1 = None
+        r1 = ingest.ingest_shard(d1, cfg1, so1, want_stats=False)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t0) / steps1
+    st1 = ingest.shard_stats(r1)
+    out["configs[1]"] = {"workload": f"FastCDC 2/8/32 KiB + SHA-256 dedupe over {n1 / 1e9:.2f} GB (the first bytes of the headline corpus), resident in HBM",
+                         "GiB_per_s": round(n1 / dt1 / 2**30, 2), "ms_per_step": round(dt1 * 1e3, 3), "steps": steps1,
+                         "frac_hbm_read_roofline": round(n1 / dt1 / 1e9 / HBM_PEAK_GBPS, 5), "chunks": st1["chunks"],
+                         "unique_chunk_ratio": round(st1["unique"] / max(1, st1["chunks"]), 4)}
+    del r1, d1
+    # configs[4], one rank: mixed corpora streamed from pinned host memory, every batch ONE replay of the hipGraph-captured chain,
+    # host -> HBM copies overlapped and INCLUDED (the reference's batch loop, README.md:1519-1580)
+    profiles = ("wikipedia", "arxiv", "news", "code")
+    per = int(os.environ.get("HMSE_BENCH_STREAM_MIB", "2048")) << 20
+    per = min(per, host.size) // seg * seg
+    bat = min(1 << 30, per)
+    tg = time.perf_counter()
+    pinned = torch.empty(per * len(profiles), dtype=torch.uint8).pin_memory()
+    for i, pr in enumerate(profiles):
+        pinned[i * per:(i + 1) * per] = torch.from_numpy(host[:per] if pr == "wikipedia" else corpus.load(pr, per, seed=42)[0])
+    t_gen = time.perf_counter() - tg
+    tot = pinned.numel()
+    w = stream.StreamIngest(cfg_full, 2 * bat, dev, graph=True)      # warm-up: capture of the batch size, allocator, module load
+    w.push(pinned[:bat]); w.push(pinned[bat: 2 * bat]); w.finish(); del w
+    torch.cuda.synchronize()
+    st = stream.StreamIngest(cfg_full, tot, dev, graph=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a0 in range(0, tot, bat):
+        st.push(pinned[a0: a0 + bat])
+    res = st.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = res.stats
+    nb = -(-tot // bat)
+    out["configs[4] on one rank"] = {
+        "workload": f"{len(profiles)} x {per / 2**30:.2f} GiB ({', '.join(profiles)}; wiki-synth profiles, seed 42) streamed from pinned host memory in {nb} batches of "
+                    f"{bat >> 20} MiB, one hipGraph replay of hmse_stream_batch per batch, host -> HBM copies overlapped and included",
+        "GiB_per_s": round(tot / dt / 2**30, 2), "ms_per_batch": round(dt / nb * 1e3, 2), "batches": nb, "bytes": tot,
+        "cf": round(tot / max(1, s["stored_bytes"] + 40 * s["unique"] + 8 * s["pointer"] + 8 * s["delta"]), 4), "chunks": s["chunks"],
+        "delta_records": s["delta"], "frac_hbm_read_roofline": round(tot / dt / 1e9 / HBM_PEAK_GBPS, 6), "corpus_gen_and_pin_s": round(t_gen, 2)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -413,6 +477,12 @@ def main():
                          "map_entries": int(cmap.shape[0]), "pointer_records": int(ptrs.shape[0]), "lba_unit": unit,
                          "scope": "hmse_manifest_pack + record/pointer prefix sums, records resident in HBM when the clock stops (rank 0)"}
         del blob, index, cmap, ptrs
+    other = None
+    if world == 1 and not distributed and a.layers == "full" and os.environ.get("HMSE_BENCH_NO_OTHER") != "1" and not a.no_other_configs:
+        try:
+            other = other_configs(data, host, dev, cfg)
+        except Exception as e:  # noqa: BLE001 — a side measurement must not lose the headline
+            other = {"error": repr(e)}
     stats = [st]
     if distributed:
         allst = [None] * world
@@ -462,6 +532,8 @@ def main():
         if manifest_info:
             out["manifest"] = manifest_info
             out["manifest_inclusive_GiB_per_s"] = round(tot["bytes"] / (dt / a.steps + manifest_info["pack_ms"] * 1e-3) / 2**30, 3)
+        if other:
+            out["other_configs"] = other
         out["stage_roofline"] = stage_roof
         if read_info:
             out["read_path"] = read_info

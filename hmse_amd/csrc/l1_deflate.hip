@@ -96,6 +96,9 @@ __device__ __forceinline__ uint32_t fixed_len(uint32_t s) { return s < 144 ? 8 :
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
 
+// workgroup barrier that orders LDS traffic only (outstanding global stores are not waited for)
+__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // order LDS traffic between the lanes of one wavefront (no instruction is emitted for the barrier itself)
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -448,7 +451,13 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     // dependent global loads: 2-8 % of a job when it is walked at the job's start.  Thread 0 walks the NEXT job's chain one link per
     // phase of THIS job (PF_STAGE below: a link is issued at one phase boundary and consumed at the next, long after it has
     // arrived) and leaves the result in sm.nx; a job starts by reading sm.nx.
+    // (This barrier separates two jobs' use of LDS; the finished job's global stores — its token list and histograms, read by a later
+    // kernel — need not have drained: __syncthreads() would wait for them, vmcnt(0), ~5 % of a job in the stamps build.)
+#ifdef HMSE_FULL_BARRIER
     __syncthreads();
+#else
+    barrier_lds_only();
+#endif
     const uint32_t ji = uni32(sm.nx.ji);   // wave-uniform, and said so: lengths and loop bounds live in SGPRs
     if (ji >= n_jobs) break;
     STAMP(10);
@@ -594,50 +603,6 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       }
       __syncthreads();  // cursor h now = end of bucket h
     }
-    // ---- phase 4a (plain jobs of the LDS classes): the matcher's hand-out order ------------------------------------
-    // A walk lasts about as many trips as its position has candidates (in-bucket index, capped at the depth), candidates per position
-    // are heavily skewed, and a job is over when its LAST walk is: handed out in rank order, the deep members of the last buckets start
-    // when the queue is nearly empty and every wavefront ends in a long, thinly occupied tail (a third of all lane-slots in the
-    // scheduling model of tools/lz_sched.py, 19 % measured).  So the ranks are handed out longest-first: four classes by candidate
-    // count (>= 24, 12..23, 4..11, 1..3), each a dense list of ranks; first-of-bucket ranks (no candidate: a third of all ranks) are
-    // not handed out at all.  The lists live in the workgroup's global scratch (no LDS left in class S): two u16[32768] buffers, two
-    // classes each, one growing up and one growing down.  Model: wave-trips per job 45.3 -> 34.1, pulls 20.3 -> 13.2 on wiki-synth;
-    // results unchanged (the order of the walks does not enter them).
-#ifdef HMSE_NO_ORD
-    constexpr bool ORD = false;   // (A/B build: round 3's hand-out in rank order)
-#else
-    constexpr bool ORD = !DICT && LDSM;
-#endif
-    uint16_t* const ordA = (uint16_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride + 98304u);
-    uint16_t* const ordB = ordA + 32768;
-    if constexpr (ORD) {
-      const uint32_t wv = uni32(wave);   // (scalar loop: the cross-lane reads below never run under a narrowed EXEC)
-      for (uint32_t r0 = wv << 6; r0 < nh; r0 += NT) {
-        const uint32_t r = r0 + lane;
-        uint32_t cls = 4;
-        if (r < nh) {
-          const uint32_t h = hash4(ld32a(W, (uint32_t)S[r]));
-          const uint32_t lo = h ? cur_get(cur, h - 1) : 0u;
-          uint32_t km = r - lo;
-          if (km > a.depth) km = a.depth;
-          cls = km >= 24u ? 0u : km >= 12u ? 1u : km >= 4u ? 2u : km >= 1u ? 3u : 4u;
-        }
-        const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u), m3 = __ballot(cls == 3u);
-        uint32_t bv = 0;
-        if (lane < 4u) {
-          const uint64_t mm = lane == 0u ? m0 : lane == 1u ? m1 : lane == 2u ? m2 : m3;
-          bv = atomicAdd(&sm.ocnt[lane], (uint32_t)__builtin_popcountll(mm));
-        }
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 1),
-                       b2 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 3);
-        if (cls < 4u) {
-          const uint64_t mm = cls == 0u ? m0 : cls == 1u ? m1 : cls == 2u ? m2 : m3;
-          const uint32_t pos = (cls == 0u ? b0 : cls == 1u ? b1 : cls == 2u ? b2 : b3) + mbcnt64(mm);
-          (cls < 2u ? ordA : ordB)[(cls & 1u) ? 32767u - pos : pos] = (uint16_t)r;
-        }
-      }
-      __syncthreads();
-    }
     STAMP(2);
     PF_STAGE(2);
     // ---- phase 4b (dictionary jobs): diagonal anchors ------------------------------------------------
@@ -739,11 +704,104 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       }
       // (no barrier needed: the state machine never touches a hinted position's slots, and the parse starts behind a barrier)
     }
+    // ---- phase 4c (LDS classes): the matcher's hand-out order ---------------------------------------------------------
+    // A walk lasts about as many trips as its position has candidates (in-bucket index, capped at the depth), candidates per position
+    // are heavily skewed, and a job is over when its LAST walk is: handed out in rank order, the deep members of the last buckets start
+    // when the queue is nearly empty and every wavefront ends in a long, thinly occupied tail (a third of all lane-slots in the
+    // scheduling model of tools/lz_sched.py, 19 % measured).  So the ranks are handed out longest-first: four classes by candidate
+    // count (>= 24, 12..23, 4..11, 1..3), each a dense list of ranks; first-of-bucket ranks (no candidate: a third of all ranks) are
+    // not handed out at all.  The lists live in the workgroup's global scratch (no LDS left in class S): two u16[32768] buffers, two
+    // classes each, one growing up and one growing down.  Model: wave-trips per job 45.3 -> 34.1, pulls 20.3 -> 13.2 on wiki-synth;
+    // results unchanged (the order of the walks does not enter them).
+    // Dictionary jobs: only chunk positions WITHOUT a diagonal hint are listed (rule 2c: the others were written by the pre-pass above);
+    // a job has ~2.6 of them per lane, so its matcher phase is as long as its longest walks make it — started first here.
+#if defined(HMSE_NO_ORD)
+    constexpr bool ORD = false;   // (A/B build: round 3's hand-out in rank order)
+#elif defined(HMSE_NO_DICT_ORD)
+    constexpr bool ORD = !DICT && LDSM;
+#else
+    constexpr bool ORD = LDSM;
+#endif
+    uint16_t* const ordA = (uint16_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride + 98304u);
+    uint16_t* const ordB = ordA + 32768;
+    if constexpr (ORD) {
+      // Two passes over this wavefront's ranks (64 per step, a step every NT ranks; ITER steps at most): the first classifies — all
+      // its LDS reads are independent and issue back to back — and counts per class in scalars; ONE LDS atomic per wavefront and class
+      // reserves the list slots; the second pass (no memory reads: the classes sit packed in registers, 3 bits each) stores the ranks.
+      // (A first version with one atomic round trip per step cost 5.5 % of a job: seven dependent LDS chains per wavefront.)
+      constexpr int ITER = (TCAP + NT - 1) / NT;
+      const uint32_t wv = uni32(wave);   // (scalar control: the cross-lane reads below never run under a narrowed EXEC)
+      uint32_t pk[(ITER + 9) / 10];
+#pragma unroll
+      for (int w = 0; w < (ITER + 9) / 10; w++) pk[w] = 0;
+      uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+      // (branch-free and staged — all S reads, then all window reads, then all cursor reads: three LDS round trips per wavefront
+      // instead of three per step; as nested ifs the compiler serialised the steps, 27 dependent round trips in class S)
+      {
+        const uint32_t last = nh ? nh - 1u : 0u;
+        constexpr int G = DICT ? 2 : ITER > 12 ? 4 : 8;   // steps staged together (registers: the larger classes run under a 64-VGPR cap)
+#pragma unroll
+        for (int g = 0; g < ITER; g += G) {
+          uint32_t pv[G], hv[G], lv[G];
+#pragma unroll
+          for (int u = 0; u < G; u++) if (g + u < ITER) { const uint32_t r = (wv << 6) + (uint32_t)(g + u) * NT + lane; pv[u] = S[r < last ? r : last]; }
+#pragma unroll
+          for (int u = 0; u < G; u++) if (g + u < ITER) hv[u] = hash4(ld32a(W, pv[u]));
+#pragma unroll
+          for (int u = 0; u < G; u++) if (g + u < ITER) lv[u] = cur_get(cur, (hv[u] - 1u) & (uint32_t)(NBK - 1));   // (= end of the bucket before; unused for bucket 0)
+#pragma unroll
+          for (int u = 0; u < G; u++) if (g + u < ITER) {
+            const int it = g + u;
+            const uint32_t r = (wv << 6) + (uint32_t)it * NT + lane;
+            uint32_t km = r - (hv[u] ? lv[u] : 0u);
+            km = km < a.depth ? km : a.depth;
+            uint32_t cls = km >= 24u ? 0u : km >= 12u ? 1u : km >= 4u ? 2u : km >= 1u ? 3u : 4u;
+            cls = r < nh ? cls : 4u;
+            if constexpr (DICT) {
+              const uint32_t pp = pv[u];
+              uint32_t bq;
+              const uint32_t bm = pp >= Dl ? hint_of(pp, (T - pp) < MAXM ? (T - pp) : MAXM, bq) : 16u;
+              cls = bm >= 16u ? 4u : cls;   // a dictionary position (a candidate only) or a hinted chunk position: no walk
+            }
+            pk[it / 10] |= cls << (3 * (it % 10));
+            n0 += (uint32_t)__builtin_popcountll(__ballot(cls == 0u)); n1 += (uint32_t)__builtin_popcountll(__ballot(cls == 1u));
+            n2 += (uint32_t)__builtin_popcountll(__ballot(cls == 2u)); n3 += (uint32_t)__builtin_popcountll(__ballot(cls == 3u));
+          }
+        }
+      }
+      uint32_t bv = 0;
+      if (lane < 4u) bv = atomicAdd(&sm.ocnt[lane], lane == 0u ? n0 : lane == 1u ? n1 : lane == 2u ? n2 : n3);
+      uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 1),
+               b2 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 3);
+#pragma unroll
+      for (int it = 0; it < ITER; it++) {
+        const uint32_t r0 = (wv << 6) + (uint32_t)it * NT;
+        if (r0 < nh) {
+          const uint32_t cls = (pk[it / 10] >> (3 * (it % 10))) & 7u;
+          const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u), m3 = __ballot(cls == 3u);
+          if (cls < 4u) {
+            const uint64_t mm = cls == 0u ? m0 : cls == 1u ? m1 : cls == 2u ? m2 : m3;
+            const uint32_t pos = (cls == 0u ? b0 : cls == 1u ? b1 : cls == 2u ? b2 : b3) + mbcnt64(mm);
+            (cls < 2u ? ordA : ordB)[(cls & 1u) ? 32767u - pos : pos] = (uint16_t)(r0 + lane);
+          }
+          b0 += (uint32_t)__builtin_popcountll(m0); b1 += (uint32_t)__builtin_popcountll(m1);
+          b2 += (uint32_t)__builtin_popcountll(m2); b3 += (uint32_t)__builtin_popcountll(m3);
+        }
+      }
+      __syncthreads();
+      STAMP(8);
+    }
     STAMP(6);
     PF_STAGE(3);
     {
       enum { FETCH = 0, PROBE = 1, EXTEND = 2, DONE = 3 };
-      constexpr uint32_t FETCH_BATCH = 16;
+#ifndef HMSE_FETCH_BATCH
+#define HMSE_FETCH_BATCH 16
+#endif
+#ifndef HMSE_FETCH_BATCH_DICT
+#define HMSE_FETCH_BATCH_DICT 8
+#endif
+      constexpr uint32_t FETCH_BATCH = DICT ? HMSE_FETCH_BATCH_DICT : HMSE_FETCH_BATCH;
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
       uint32_t pkey = 0;   // classes with the filter array: this position's own filter byte
@@ -799,7 +857,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           break;
         }
         uint64_t need = uni64(__ballot(st == FETCH));
-        if constexpr (DICT) {
+        if constexpr (DICT && !ORD) {
           // serve the idle lanes from the wavefront's window; scan the next 64 sorted ranks when it is empty.  Everything that
           // steers this loop (need, wq_mask, wq_base, wq_done, nh_s) is wave-uniform AND scalar (uni32 / uni64)
           for (int it = 0; need != 0 && it < 6; it++) {
@@ -985,34 +1043,63 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         const uint32_t sw = wave * SEG;
         const uint32_t send = (sw + SEG) < L ? (sw + SEG) : L;
         uint32_t curp = sw;
-        for (uint32_t wb = sw; wb < send; wb += 64) {
-          const uint32_t x = wb + lane;
-          const uint32_t nv = x < L ? (uint32_t)jump[x] : L;
-          const uint32_t wend = (wb + 64) < send ? (wb + 64) : send;
-          // Pointer doubling inside the window instead of a serial chain: after round r lane j knows the first 2^r
-          // positions of the path that starts at j (a 64-bit mask) and where that path stands (its 2^r-th successor, or
-          // the position at which it left the window).  <= 6 rounds of three lane gathers; the walk itself is then two
-          // v_readlane at the entry.
-          uint32_t hop = nv;
-          uint32_t rlo = lane < 32 ? 1u << lane : 0u, rhi = lane >= 32 ? 1u << (lane - 32) : 0u;
+        // Pointer doubling inside a 64-position window instead of a serial chain: after round r lane j knows the first 2^r
+        // positions of the path that starts at j (a 64-bit mask) and where that path stands (its 2^r-th successor, or
+        // the position at which it left the window).  <= 6 rounds of three lane gathers; the walk itself is then two
+        // v_readlane at the entry.  The doubling of a window does not depend on the walk's entry into it, so PW windows are
+        // doubled TOGETHER (their gathers are independent: one LDS-crossbar round trip serves PW windows) and the entries are
+        // resolved afterwards, in order (round 4: the walks were 8 % of a plain job, all of it the latency of 6 x 3 dependent
+        // ds_bpermute per window).
+        constexpr int PW = 3;
+#ifdef HMSE_DFL_PW1
+        constexpr int PWX = 1;
+#else
+        constexpr int PWX = PW;
+#endif
+        const uint32_t sw_s = uni32(sw), send_s = uni32(send);   // (wave-uniform, and said so: the window loop is a scalar loop)
+        for (uint32_t wb0 = sw_s; wb0 < send_s; wb0 += 64u * PWX) {
+          uint32_t hop[PWX], rlo[PWX], rhi[PWX], wendv[PWX];
+#pragma unroll
+          for (int u = 0; u < PWX; u++) {
+            const uint32_t wb = wb0 + 64u * u;
+            const uint32_t x = wb + lane;
+            hop[u] = (wb < send_s && x < L) ? (uint32_t)jump[x] : L;
+            wendv[u] = (wb + 64) < send_s ? (wb + 64) : send_s;
+            rlo[u] = lane < 32 ? 1u << lane : 0u; rhi[u] = lane >= 32 ? 1u << (lane - 32) : 0u;
+          }
 #pragma nounroll
           for (int r = 0; r < 6; r++) {
-            const bool inside = hop < wend;
-            if (__ballot(inside) == 0) break;
-            const int src = (int)(inside ? hop - wb : lane);
-            const uint32_t h2 = (uint32_t)__shfl((int)hop, src, 64);
-            const uint32_t l2 = (uint32_t)__shfl((int)rlo, src, 64), g2 = (uint32_t)__shfl((int)rhi, src, 64);
-            rlo |= inside ? l2 : 0u;
-            rhi |= inside ? g2 : 0u;
-            hop = inside ? h2 : hop;
+            bool inside[PWX], any = false;
+#pragma unroll
+            for (int u = 0; u < PWX; u++) { inside[u] = (wb0 + 64u * u) < send_s && hop[u] < wendv[u]; any = any || inside[u]; }
+            if (__ballot(any) == 0) break;
+            uint32_t h2[PWX], l2[PWX], g2[PWX];
+#pragma unroll
+            for (int u = 0; u < PWX; u++) {
+              const int src = (int)(inside[u] ? hop[u] - (wb0 + 64u * u) : lane);
+              h2[u] = (uint32_t)__shfl((int)hop[u], src, 64);
+              l2[u] = (uint32_t)__shfl((int)rlo[u], src, 64); g2[u] = (uint32_t)__shfl((int)rhi[u], src, 64);
+            }
+#pragma unroll
+            for (int u = 0; u < PWX; u++) {
+              rlo[u] |= inside[u] ? l2[u] : 0u;
+              rhi[u] |= inside[u] ? g2[u] : 0u;
+              hop[u] = inside[u] ? h2[u] : hop[u];
+            }
           }
-          uint64_t m = 0;
-          if (curp < wend) {
-            const int el = (int)(curp - wb);
-            m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi, el) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rlo, el);
-            curp = (uint32_t)__builtin_amdgcn_readlane((int)hop, el);
+#pragma unroll
+          for (int u = 0; u < PWX; u++) {
+            const uint32_t wb = wb0 + 64u * u;
+            if (wb < send_s) {
+              uint64_t m = 0;
+              if (curp < wendv[u]) {
+                const int el = (int)(curp - wb);
+                m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rhi[u], el) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rlo[u], el);
+                curp = (uint32_t)__builtin_amdgcn_readlane((int)hop[u], el);
+              }
+              mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32);  // every lane, same words (no lane-dependent branch at a loop tail)
+            }
           }
-          mark[wb >> 5] = (uint32_t)m; mark[(wb >> 5) + 1] = (uint32_t)(m >> 32);  // every lane, same words (no lane-dependent branch at a loop tail)
         }
         sm.pexit[wave] = curp;  // every lane, same value
       }

@@ -176,6 +176,9 @@ def parse_manifest(m: Manifest) -> dict:
     return {"kind": slot_kind, "base": base, "base_shard": base_shard, "stream_off": s_off, "stream_len": s_len, "raw_len": raw_len}
 
 
+MAX_DELTA_DEPTH_LOG2 = 16     # a dictionary chain of more than 65536 records is refused as corrupt (read.dependency_order)
+
+
 def dependency_order(base: np.ndarray):
     """Records in (shard, slot) order with `base[k]` = the record holding k's dictionary (-1 none).  hmse_l1_inflate wants a
     dictionary to PRECEDE its dependants; that holds as stored except in the store of a multi-rank stream ingested with global L4,
@@ -184,14 +187,20 @@ def dependency_order(base: np.ndarray):
     n = len(base)
     if n == 0 or (base < np.arange(n)).all():
         return None
-    depth = np.zeros(n, np.int64)
-    for _ in range(n):
-        nd = np.where(base >= 0, depth[np.maximum(base, 0)] + 1, 0)
-        if np.array_equal(nd, depth):
+    # depth of every record in the dictionary forest by POINTER DOUBLING: after round r, `anc` is the 2^r-th ancestor (n = past the
+    # root) and `depth` counts the links walked so far — ceil(log2(longest chain)) + 1 numpy passes instead of one pass per level
+    # (a long version chain of a global-L4 stream store cost O(n * depth); a corrupt store with a cycle O(n^2) before it was refused).
+    anc = np.where(base >= 0, base, n).astype(np.int64)
+    anc = np.concatenate([anc, np.array([n], np.int64)])      # the sentinel is its own ancestor
+    depth = (anc[:n] < n).astype(np.int64)
+    for _ in range(MAX_DELTA_DEPTH_LOG2 + 1):
+        live = anc[:n] < n
+        if not live.any():
             break
-        depth = nd
+        depth = depth + np.where(live, np.concatenate([depth, [0]])[anc[:n]], 0)
+        anc[:n] = anc[anc[:n]]
     else:
-        raise ReadError("the DELTA records' dictionaries form a cycle")
+        raise ReadError(f"the DELTA records' dictionaries form a cycle (or a chain longer than {1 << MAX_DELTA_DEPTH_LOG2} records)")
     order = np.argsort(depth, kind="stable")
     new_of_old = np.empty(n, np.int64)
     new_of_old[order] = np.arange(n)

@@ -191,7 +191,7 @@ class StreamIngest:
         """The ONE host read of the chain: counts after the batches enqueued so far."""
         st = self._state.tolist()
         if st[7]:
-            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 exchange row, bit4 workspace not initialised, "
+            raise ValueError(f"streaming chain status {st[7]:#x}: bit0 chunk capacity, bit1 stored-chunk capacity, bit2 L2, bit3 exchange row, bit4 workspace not initialised, bit5 state block inconsistent ([8] != [1] on one rank), "
                              "bits 8.. DEFLATE (0x100 stream capacity, 0x200 workspace); the failing batch and every later one were dropped "
                              f"({st[0]} bytes / {st[1]} chunks are intact)")
         self.n_done, self.n_chunks, self.n_unique, self.stream_bytes = st[0], st[1], st[3], st[5]

@@ -217,21 +217,22 @@ def test_a_one_rank_state_block_whose_global_count_disagrees_is_refused(dev):
     import torch
     from hmse_amd import IngestConfig, corpus, stream
     cfg = IngestConfig(seg_size=1 << 20)
-    data = corpus.wiki_synth(4 << 20, seed=6)
+    data = corpus.wiki_synth(6 << 20, seed=6)
     B = 2 << 20
     s = stream.StreamIngest(cfg, data.size, dev, graph=True)
     s.push(torch.from_numpy(data[:B].copy()))
+    s.push(torch.from_numpy(data[B: 2 * B].copy()))                    # (a push processes the piece pushed before it)
     torch.cuda.synchronize()
     st0 = s._state.tolist()
-    assert st0[7] == 0 and st0[8] == st0[1] > 0
+    assert st0[7] == 0 and st0[8] == st0[1] > 0 and st0[0] == B
     digests = s._digests[: st0[1]].clone()
     s._state[8] = 0                                                     # what a version-1 caller's resume would have left there
-    s.push(torch.from_numpy(data[B:].copy()))
+    s.push(torch.from_numpy(data[2 * B:].copy()))                       # processes the second piece against the bad state block
     with pytest.raises(ValueError, match="status"):
         s.finish()
     st = s._state.tolist()
     assert st[7] & 32, hex(st[7])
-    assert st[1] == st0[1] and st[3] == st0[3] and st[5] == st0[5]      # counters frozen at the last good batch
+    assert st[0] == B and st[1] == st0[1] and st[3] == st0[3] and st[5] == st0[5]      # counters frozen at the last good batch
     assert torch.equal(s._digests[: st0[1]], digests)                   # and nothing was overwritten
 
 

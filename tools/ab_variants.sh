@@ -4,7 +4,7 @@
 BYTES=$1; shift
 for V in "$@"; do
   if [ "$V" = base ]; then unset HMSE_LIB_VARIANT; else export HMSE_LIB_VARIANT=$V; fi
-  HMSE_BENCH_NO_VERIFY=1 HMSE_BENCH_NO_MANIFEST=1 timeout -k 5 300 python bench.py --bytes $BYTES --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab_$V.json 2> gpurun_out/ab_$V.err || { echo "$V FAILED"; tail -3 gpurun_out/ab_$V.err; continue; }
+  HMSE_BENCH_NO_VERIFY=1 HMSE_BENCH_NO_MANIFEST=1 timeout -k 5 300 python bench.py --bytes $BYTES --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs > gpurun_out/ab_$V.json 2> gpurun_out/ab_$V.err || { echo "$V FAILED"; tail -3 gpurun_out/ab_$V.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$V.json")); sr=d["stage_roofline"]

@@ -7,7 +7,8 @@ import torch
 
 from hmse_amd import IngestConfig, _lib, corpus, ops
 
-_lib.HIP_LIB_PATH = _lib.HIP_LIB_PATH.replace("libhmse_hip.so", "libhmse_hip_stamps.so")
+import os
+_lib.HIP_LIB_PATH = _lib.HIP_LIB_PATH.replace("libhmse_hip.so", os.environ.get("HMSE_STAMPS_LIB", "libhmse_hip_stamps.so"))
 lib = _lib.hip_lib()
 lib.hmse_debug_deflate_stamps.argtypes = [C.c_void_p, C.c_int]
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -30,7 +31,7 @@ lib.hmse_debug_deflate_stamps(buf.ctypes.data, 0)
 ebuf = np.zeros(8, dtype=np.uint64)
 lib.hmse_debug_encode_stamps.argtypes = [C.c_void_p, C.c_int]
 lib.hmse_debug_encode_stamps(ebuf.ctypes.data, 0)
-names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match: state machine", "4 parse: stitch", "5 tokens + histograms", "6 match: anchors + hinted positions", "7 -", "8 -", "9 record out", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
+names = ["0 load+clear", "1 hist+scan", "2 scatter+rank", "3 match: state machine", "4 parse: stitch", "5 tokens + histograms", "6 match: anchors + hinted positions", "7 -", "8 hand-out order lists", "9 record out", "10 job fetch", "11 parse: next-pointers", "12 parse: speculative walks"]
 lens = (cuts[1:] - cuts[:-1])[uniq]
 hb = base >= 0
 Tfull = lens
