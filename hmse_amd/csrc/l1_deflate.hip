@@ -96,9 +96,6 @@ __device__ __forceinline__ uint32_t fixed_len(uint32_t s) { return s < 144 ? 8 :
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
 
-// workgroup barrier that orders LDS traffic only (outstanding global stores are not waited for)
-__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // order LDS traffic between the lanes of one wavefront (no instruction is emitted for the barrier itself)
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -451,13 +448,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     // dependent global loads: 2-8 % of a job when it is walked at the job's start.  Thread 0 walks the NEXT job's chain one link per
     // phase of THIS job (PF_STAGE below: a link is issued at one phase boundary and consumed at the next, long after it has
     // arrived) and leaves the result in sm.nx; a job starts by reading sm.nx.
-    // (This barrier separates two jobs' use of LDS; the finished job's global stores — its token list and histograms, read by a later
-    // kernel — need not have drained: __syncthreads() would wait for them, vmcnt(0), ~5 % of a job in the stamps build.)
-#ifdef HMSE_FULL_BARRIER
+    // (Measured, round 4: a barrier here that waits for LDS traffic only — the finished job's global stores need not have drained —
+    // changes nothing: 39.4 against 39.5 ms of plain kernels at 2 GB; the second workgroup of the CU fills the wait.)
     __syncthreads();
-#else
-    barrier_lds_only();
-#endif
     const uint32_t ji = uni32(sm.nx.ji);   // wave-uniform, and said so: lengths and loop bounds live in SGPRs
     if (ji >= n_jobs) break;
     STAMP(10);
@@ -804,6 +797,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       constexpr uint32_t FETCH_BATCH = DICT ? HMSE_FETCH_BATCH_DICT : HMSE_FETCH_BATCH;
       uint32_t st = FETCH, i = 0, p = 0, kk = 0, kmax = 0, best = 0, bd = 0, probe = 0, maxlen = 0, ml = 0, q = 0, qn = 0, kn = 0;
       uint32_t pw0 = 0, pw1 = 0;
+#ifndef HMSE_NO_PROBE16
+      uint32_t pw2 = 0, pw3 = 0;   // bytes 8..15 of the position: a candidate that agrees on 8 bytes is compared on 8 more in the same trip
+#endif
       uint32_t pkey = 0;   // classes with the filter array: this position's own filter byte
       // Can candidate with filter byte kb be skipped without a window read?  Filter array classes: kb = (byte 4 & 15) | 4 further
       // bits of the hash product << 4 — a candidate whose high nibble differs holds a DIFFERENT 4-gram in the same bucket
@@ -825,7 +821,11 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         i = ii; p = pp;
         qn = i ? S[i - 1] : 0u;  // first candidate (used iff kmax != 0)
         kn = NOK ? (uint32_t)W[qn + 4] : (i ? (uint32_t)K[i - 1] : 0u);  // its byte 4 (class SG2 has no filter array)
+#ifndef HMSE_NO_PROBE16
+        { uint64_t pp__[2]; ldNa<2>(W, p, pp__); pw0 = (uint32_t)pp__[0]; pw1 = (uint32_t)(pp__[0] >> 32); pw2 = (uint32_t)pp__[1]; pw3 = (uint32_t)(pp__[1] >> 32); }
+#else
         ld64a(W, p, pw0, pw1);
+#endif
         const uint32_t hxp = pw0 * 0x9E3779B1u;
         const uint32_t h = hxp >> (32 - HB);
         pkey = (pw1 & 0x0Fu) | ((hxp >> 12) & 0xF0u);
@@ -927,6 +927,14 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         }
 #endif
         bool fin = false;  // candidate kk finished with length ml
+#ifdef HMSE_EXT_MIN
+        // (experiment) the EXTEND block's ~120 instructions are issued for the whole wavefront however few lanes extend: run it only when
+        // HMSE_EXT_MIN lanes wait for it, or nothing else can run
+        const uint64_t em__ = uni64(__ballot(st == EXTEND));
+        const bool run_ext = (uint32_t)__builtin_popcountll(em__) >= (uint32_t)HMSE_EXT_MIN || uni64(__ballot(st == PROBE)) == 0;
+#else
+        constexpr bool run_ext = true;
+#endif
         if (st == PROBE) {
           q = qn;
           uint32_t kb = kn;
@@ -951,9 +959,22 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
             if (cprobe != probe) { }                                   // cannot beat the current best
             else if ((x = c0 ^ pw0) != 0) ml = (uint32_t)__builtin_ctz(x) >> 3;
             else if ((x = c1 ^ pw1) != 0) ml = 4 + ((uint32_t)__builtin_ctz(x) >> 3);
+#ifndef HMSE_NO_PROBE16
+            else if (maxlen > 8) {
+              // 8 bytes agree: 8 more at once (95 % of such candidates end there on text: tools/lz_study "extend trips at 32 / 16 / 8 B"),
+              // so the EXTEND block — ~55 vector instructions issued for the whole wavefront, for ~4 lanes — is entered by the rare
+              // candidate that agrees on 16 bytes, and a match of 8..15 bytes costs no trip of its own
+              uint32_t c2, c3;
+              ld64a(W, q + 8, c2, c3);
+              if ((x = c2 ^ pw2) != 0) ml = 8 + ((uint32_t)__builtin_ctz(x) >> 3);
+              else if ((x = c3 ^ pw3) != 0) ml = 12 + ((uint32_t)__builtin_ctz(x) >> 3);
+              else { ml = 16; if (maxlen > 16) { fin = false; st = EXTEND; } }
+            } else ml = 8;
+#else
             else { ml = 8; if (maxlen > 8) { fin = false; st = EXTEND; } }
+#endif
           }
-        } else if (st == EXTEND) {
+        } else if (st == EXTEND && run_ext) {
           // 32 bytes per trip, all reads of each side issued together (one LDS round trip): the dictionary jobs
           // (near-duplicate chunks) spend most of their trips here, a full-length match is 258 bytes
           // (64 bytes where the class runs one workgroup per CU and so may use 128 VGPRs: SG3 and B, the classes of the
@@ -1046,16 +1067,14 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         // Pointer doubling inside a 64-position window instead of a serial chain: after round r lane j knows the first 2^r
         // positions of the path that starts at j (a 64-bit mask) and where that path stands (its 2^r-th successor, or
         // the position at which it left the window).  <= 6 rounds of three lane gathers; the walk itself is then two
-        // v_readlane at the entry.  The doubling of a window does not depend on the walk's entry into it, so PW windows are
-        // doubled TOGETHER (their gathers are independent: one LDS-crossbar round trip serves PW windows) and the entries are
-        // resolved afterwards, in order (round 4: the walks were 8 % of a plain job, all of it the latency of 6 x 3 dependent
-        // ds_bpermute per window).
-        constexpr int PW = 3;
-#ifdef HMSE_DFL_PW1
-        constexpr int PWX = 1;
-#else
-        constexpr int PWX = PW;
+        // v_readlane at the entry.  The doubling of a window does not depend on the walk's entry into it, so PWX windows can be
+        // doubled TOGETHER (independent gathers: one LDS-crossbar round trip serves PWX windows) and the entries resolved afterwards,
+        // in order.  Measured, round 4: three windows together are 1.8 % SLOWER on the plain kernels (38.8 -> 39.5 ms at 2 GB) —
+        // the walks' latency is already hidden behind the CU's other workgroup, the extra registers and selects are not.
+#ifndef HMSE_DFL_PW
+#define HMSE_DFL_PW 1
 #endif
+        constexpr int PWX = HMSE_DFL_PW;
         const uint32_t sw_s = uni32(sw), send_s = uni32(send);   // (wave-uniform, and said so: the window loop is a scalar loop)
         for (uint32_t wb0 = sw_s; wb0 < send_s; wb0 += 64u * PWX) {
           uint32_t hop[PWX], rlo[PWX], rhi[PWX], wendv[PWX];

@@ -193,7 +193,6 @@ class DistStreamIngest:
             # this rank is a no-op), the rank keeps taking part in the collectives with empty rows, and read_state()'s
             # all-reduce(MAX) of the status makes EVERY rank raise at finish() — this one with the reason.
             self._host_error = self._host_error or err
-            self._state[7:8] |= 64
             n, host_piece = 0, host_piece[:0]
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
@@ -202,6 +201,8 @@ class DistStreamIngest:
             ev.record(self.copy_stream)
         while self.pending:
             self._process(*self.pending.pop(0))
+        if err:
+            self._state[7:8] |= 64      # (behind the piece pushed before, which is still good)
         self.pending.append((self.n_bytes, n, ev))
         self.n_bytes += n
 

@@ -140,7 +140,9 @@ static void walk_trips(const idx_t* x, uint32_t p, uint32_t D, int fmode, uint32
     out[4]++;
     uint32_t ml = 0;
     while (ml < maxlen && x->W[q + ml] == x->W[p + ml]) ml++;
-    if (ml >= 8 && maxlen > 8) { uint32_t e = 8; do { out[1]++; e += 32; } while (e <= ml && e < maxlen); }
+    if (ml >= 8 && maxlen > 8) { uint32_t e = 8; do { out[1]++; e += 32; } while (e <= ml && e < maxlen);
+      e = 8; do { out[5]++; e += 16; } while (e <= ml && e < maxlen); e = 8; do { out[6]++; e += 8; } while (e <= ml && e < maxlen);
+      out[7] += ml < 16; }
     if (ml > best) { best = ml; if (ml == maxlen) break; }
     kk++;
   }
