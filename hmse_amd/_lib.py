@@ -24,6 +24,15 @@ class HmseCfg(C.Structure):
         "level", "chain_depth", "layers", "delta_max_ratio_pct")]
 
 
+class HmseGl4(C.Structure):
+    """Mirror of `hmse_gl4` (include/hmse.h): the global-L4 arrays of a multi-rank stream (device pointers and capacities)."""
+
+    _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("rank", C.c_uint32), ("reserved", C.c_uint32),
+                ("sig_cap", C.c_uint64), ("max_stored_g", C.c_uint64), ("gstate", C.c_void_p), ("sig_g", C.c_void_p), ("band_keys_g", C.c_void_p),
+                ("base_g", C.c_void_p), ("lsh_tables_g", C.c_void_p), ("lsh_slots_g", C.c_uint64), ("g_owner", C.c_void_p), ("g_local", C.c_void_p),
+                ("ug", C.c_void_p), ("base_global", C.c_void_p), ("req_counts", C.c_void_p), ("req_slots", C.c_void_p), ("ghost_chunk0", C.c_uint64)]
+
+
 def build(force: bool = False) -> None:
     """Compile every HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     args = ["make", "-C", _CSRC, "-s", "-j8"]
@@ -107,6 +116,17 @@ def hip_lib():
         L.hmse_stream_piece_encode.restype = C.c_int
         L.hmse_stream_piece_encode.argtypes = [_VP, _U64, _U64, _U64, cfgp, _VP, _VP, _U32, _U32, _VP, _VP, _VP, _U64, _VP, _VP, _VP, _U64, _VP, _U64,
                                                _VP, _VP, _VP, _VP, _U64, _VP, _VP, _VP, _U64, _VP, _SZ, _VP]
+        L.hmse_stream_sig_cap.restype = _U64
+        L.hmse_stream_sig_cap.argtypes = [_U64, cfgp]
+        L.hmse_stream_sig_row_bytes.restype = _U64
+        L.hmse_stream_sig_row_bytes.argtypes = [_U64, cfgp]
+        L.hmse_stream_piece_sign.restype = C.c_int
+        L.hmse_stream_piece_sign.argtypes = [_VP, _U64, _U64, _U64, cfgp, _VP, _VP, _U32, _U32, _VP, _VP, _VP, _U64, _VP, _VP, _VP, _U64, _VP, _U64,
+                                             _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_stream_piece_bases.restype = C.c_int
+        L.hmse_stream_piece_bases.argtypes = [_U64, cfgp, _VP, _VP, C.POINTER(HmseGl4), _VP, _VP, _VP, _VP, _SZ, _VP]
+        L.hmse_stream_piece_encode_g.restype = C.c_int
+        L.hmse_stream_piece_encode_g.argtypes = [_VP, _U64, _U64, _U64, cfgp, _VP, _VP, _VP, _VP, _VP, _VP, _U64, _VP, _SZ, _VP]
         L.hmse_manifest_pack.restype = C.c_int
         L.hmse_manifest_pack.argtypes = [_VP, _VP, _VP, _VP, _VP, _U64, _VP, _VP, _VP, _U64, _VP, _U64, _U32, _VP, _U32, _VP, _U32, _VP,
                                          _VP, _U64, _VP, _VP, _VP, _U64, _VP, _VP, _SZ, _VP]
@@ -138,4 +158,4 @@ EXPORTED_SYMBOLS = (
     "hmse_cfg_default", "hmse_cfg_validate", "hmse_abi_version", "hmse_strerror", "hmse_gear_table",
     "hmse_workspace_bytes", "hmse_l2_cdc", "hmse_l3_sha256", "hmse_l3_dedup", "hmse_l3_index_slots", "hmse_l3_index_update",
     "hmse_l4_lsh_slots", "hmse_l4_lsh_update", "hmse_l4_minhash",
-    "hmse_l4_lsh", "hmse_l1_deflate", "hmse_l1_deflate_ex", "hmse_l1_deflate_record_bytes", "hmse_l1_deflate_record_bytes_dict", "hmse_l1_inflate", "hmse_l1_inflate_mode", "hmse_read_assemble", "hmse_manifest_pack", "hmse_manifest_pack_ex", "hmse_stream_batch", "hmse_stream_batch_workspace_bytes", "hmse_stream_workspace_init", "hmse_stream_row_bytes", "hmse_stream_piece_hash", "hmse_stream_piece_encode", "hmse_profile_enable", "hmse_profile_read", "hmse_profile_counter")
+    "hmse_l4_lsh", "hmse_l1_deflate", "hmse_l1_deflate_ex", "hmse_l1_deflate_record_bytes", "hmse_l1_deflate_record_bytes_dict", "hmse_l1_inflate", "hmse_l1_inflate_mode", "hmse_read_assemble", "hmse_manifest_pack", "hmse_manifest_pack_ex", "hmse_stream_batch", "hmse_stream_batch_workspace_bytes", "hmse_stream_workspace_init", "hmse_stream_row_bytes", "hmse_stream_piece_hash", "hmse_stream_piece_encode", "hmse_stream_sig_cap", "hmse_stream_sig_row_bytes", "hmse_stream_piece_sign", "hmse_stream_piece_bases", "hmse_stream_piece_encode_g", "hmse_profile_enable", "hmse_profile_read", "hmse_profile_counter")

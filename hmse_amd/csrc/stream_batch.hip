@@ -147,6 +147,115 @@ __global__ void advance_kernel(uint64_t* st, uint64_t piece_bytes) {
   st[SB_G_OLD] += st[SB_G_NEW];
 }
 
+// ---- global L4 for a multi-rank stream as captured phases (round 4; SURVEY.md §8f-3 "cross-GPU base-chunk fetch ... for global L4") ----
+// The stream's stored chunks of ALL ranks are numbered in global stored order (batch, rank, local); every rank keeps the same
+// signature array, band tables and owner map of that numbering, so every rank finds the same dictionary for every chunk as ONE rank
+// ingesting the whole stream would.  Per batch, between the digest exchange and DEFLATE:
+//   hmse_stream_piece_sign    rows of all ranks -> global index -> this rank's new stored chunks -> MinHash -> the rank's SIGNATURE ROW
+//                             {u64 count, u64 first local stored slot, 16 B pad, sig_cap x 512 B}: fixed size, like the digest row
+//   (all-gather of the signature rows)
+//   hmse_stream_piece_bases   rows -> global signature array / owner map -> global band tables -> dictionary of each of this rank's new
+//                             chunks: own (a chunk id), or REMOTE -> a request (owner, owner's stored slot), grouped by owner
+//   (the remote dictionaries are fetched — the one step that stays eager: its all-to-alls are sized by the request counts)
+//   hmse_stream_piece_encode_g  DEFLATE (a fetched dictionary is chunk ghost_chunk0 + j of the cut array) -> tails -> both states advance
+constexpr uint32_t SIG_HDR = 32;
+constexpr uint32_t SIG_BYTES = 512;   // 128 x u32 (the device path is specialised to n_hashes = 128)
+
+// this rank's new signatures (sig_all[u_old .. u_old + u_new)) -> its exchange row; a batch with more new stored chunks than a row holds
+// is dropped with status bit 7
+__global__ __launch_bounds__(256) void sig_row_kernel(const uint32_t* __restrict__ sig_all, uint64_t* st, uint64_t sig_cap, uint8_t* __restrict__ row) {
+  const uint64_t u_old = st[SB_U_OLD];
+  uint64_t u_new = st[SB_U_NEW];
+  const bool over = u_new > sig_cap;
+  if (over || st[SB_STATUS]) u_new = 0;
+  const uint4* src = (const uint4*)(sig_all + 128 * u_old);
+  uint4* dst = (uint4*)(row + SIG_HDR);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < u_new * (SIG_BYTES / 16); i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ((uint64_t*)row)[0] = u_new; ((uint64_t*)row)[1] = u_old;
+    if (over && !st[SB_STATUS]) { st[SB_STATUS] |= 128ull; st[SB_U_NEW] = 0; st[SB_N_NEW] = 0; }
+  }
+}
+
+// signature rows of all ranks -> sig_g[ug_old + prefix(rank) + j], owner map; gst[SB_U_NEW] = total, gst[SB_G_BASE] = this rank's first
+__global__ __launch_bounds__(256) void ingest_sig_rows_kernel(const uint8_t* __restrict__ rows, uint64_t row_bytes, uint32_t world, uint32_t rank,
+                                                               uint64_t sig_cap, uint32_t* __restrict__ sig_g, uint32_t* __restrict__ g_owner,
+                                                               uint64_t* __restrict__ g_local, uint64_t max_stored_g, uint64_t* gst, uint64_t* st) {
+  const uint64_t ug_old = gst[SB_U_OLD];
+  uint64_t total = 0, mine_before = 0;
+  bool bad = false;
+  for (uint32_t q = 0; q < world; q++) {
+    uint64_t c = *(const uint64_t*)(rows + (size_t)q * row_bytes);
+    if (c > sig_cap) { bad = true; c = 0; }
+    if (q < rank) mine_before += c;
+    total += c;
+  }
+  const bool over = ug_old + total > max_stored_g;
+  const bool dead = st[SB_STATUS] != 0;
+  if (bad || over || dead) total = 0;
+  if (total) {
+    uint64_t before = 0;
+    for (uint32_t q = 0; q < world; q++) {
+      const uint8_t* row = rows + (size_t)q * row_bytes;
+      const uint64_t c = ((const uint64_t*)row)[0], lo = ((const uint64_t*)row)[1];
+      const uint4* src = (const uint4*)(row + SIG_HDR);
+      uint4* dst = (uint4*)(sig_g + 128 * (ug_old + before));
+      for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < c * (SIG_BYTES / 16); i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+      for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < c; j += (uint64_t)gridDim.x * 256) { g_owner[ug_old + before + j] = q; g_local[ug_old + before + j] = lo + j; }
+      before += c;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    gst[SB_U_NEW] = total;
+    gst[SB_G_BASE] = ug_old + mine_before;
+    if (!dead && (bad || over)) { st[SB_STATUS] |= bad ? 8ull : 2ull; st[SB_U_NEW] = 0; st[SB_N_NEW] = 0; }
+  }
+}
+
+// dictionary of every new stored chunk of this rank: own -> its chunk id; remote -> ghost chunk ghost0 + j and request j = (owner, slot),
+// requests grouped by owner (counts[q], counts[world] = total).  One workgroup.
+__global__ __launch_bounds__(1024) void resolve_bases_kernel(const int64_t* __restrict__ base_g, const uint32_t* __restrict__ keys_g, uint32_t bands,
+                                                              const uint32_t* __restrict__ g_owner, const uint64_t* __restrict__ g_local,
+                                                              const uint64_t* __restrict__ uniq_all, uint32_t world, uint32_t rank, uint64_t ghost0,
+                                                              const uint64_t* gst, const uint64_t* st, uint64_t* __restrict__ ug, int64_t* __restrict__ base_global,
+                                                              int64_t* __restrict__ base_all, uint32_t* __restrict__ band_keys, uint64_t* __restrict__ sel_ids,
+                                                              int64_t* __restrict__ sel_base, uint64_t* __restrict__ n_sel, uint64_t* __restrict__ req_counts,
+                                                              uint64_t* __restrict__ req_slots) {
+  __shared__ uint32_t cnt[256], cur[256];
+  const uint64_t u_old = st[SB_U_OLD], m0 = gst[SB_G_BASE];
+  const uint64_t nu = (st[SB_STATUS] || gst[SB_U_NEW] == 0) ? 0ull : st[SB_U_NEW];
+  const uint32_t t = threadIdx.x;
+  if (t < 256) { cnt[t] = 0; cur[t] = 0; }
+  __syncthreads();
+  for (uint64_t k = t; k < nu; k += 1024) {
+    const int64_t bg = base_g[m0 + k];
+    if (bg >= 0 && g_owner[bg] != rank) atomicAdd(&cnt[g_owner[bg]], 1u);
+  }
+  __syncthreads();
+  if (t == 0) { uint32_t run = 0; for (uint32_t q = 0; q < world; q++) { const uint32_t c = cnt[q]; req_counts[q] = c; cur[q] = run; run += c; } req_counts[world] = run; *n_sel = nu; }
+  __syncthreads();
+  for (uint64_t k = t; k < nu; k += 1024) {
+    const uint64_t gi = m0 + k;
+    const int64_t bg = base_g[gi];
+    ug[u_old + k] = gi; base_global[u_old + k] = bg;
+    for (uint32_t b = 0; b < bands; b++) band_keys[(u_old + k) * bands + b] = keys_g[gi * bands + b];
+    sel_ids[k] = uniq_all[u_old + k];
+    int64_t bl = -1, bc = -1;
+    if (bg >= 0) {
+      const uint32_t ow = g_owner[bg];
+      const uint64_t loc = g_local[bg];
+      if (ow == rank) { bl = (int64_t)loc; bc = (int64_t)uniq_all[loc]; }
+      else { const uint32_t j = atomicAdd(&cur[ow], 1u); req_slots[j] = loc; bc = (int64_t)(ghost0 + j); }
+    }
+    base_all[u_old + k] = bl; sel_base[k] = bc;
+  }
+}
+
+__global__ void advance_g_kernel(uint64_t* gst, const uint64_t* st) {
+  if (st[SB_STATUS]) return;
+  gst[SB_U_OLD] += gst[SB_U_NEW];
+}
+
 struct Ws {
   uint64_t* cuts_local; uint64_t* n_cuts; uint32_t* l2_status; uint64_t* sel_ids; int64_t* sel_base; uint64_t* n_sel;
   uint64_t* out_off; uint8_t* kind; uint32_t* dfl_status; uint8_t* row;
@@ -323,4 +432,88 @@ extern "C" int hmse_stream_batch(uint8_t* data, uint64_t data_cap, uint64_t batc
   return piece_encode(data, data_cap, batch_bytes, batch_bytes, cfg, state, w.row, 1u, 0u, cuts_all, nullptr, digests_all, max_chunks, first_occ, refcount,
                       l3_table, l3_slots, uniq_all, max_unique, sig_all, band_keys, base_all, lsh_tables, lsh_slots, kind_all, stream_off_all, out,
                       out_cap, w, stream);
+}
+
+
+// ---- global L4 as captured phases (see the kernels above) ----------------------------------------------------------------------
+static uint64_t sb_sig_cap(uint64_t cap_bytes, const hmse_cfg* cfg) { return 2 * (cap_bytes / cfg->avg_size) + 64; }   // twice the expected stored chunks of a piece
+
+extern "C" uint64_t hmse_stream_sig_cap(uint64_t cap_bytes, const hmse_cfg* cfg) {
+  return (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0) ? 0 : sb_sig_cap(cap_bytes, cfg);
+}
+extern "C" uint64_t hmse_stream_sig_row_bytes(uint64_t cap_bytes, const hmse_cfg* cfg) {
+  return (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0) ? 0 : sb::SIG_HDR + sb::SIG_BYTES * sb_sig_cap(cap_bytes, cfg);
+}
+
+static bool gl4_ok(const hmse_gl4* g) {
+  return g && g->struct_size == sizeof(hmse_gl4) && g->world >= 1 && g->world <= 256 && g->rank < g->world && g->gstate && g->sig_g && g->band_keys_g &&
+         g->base_g && g->lsh_tables_g && g->g_owner && g->g_local && g->ug && g->base_global && g->req_counts && g->req_slots && g->max_stored_g;
+}
+
+extern "C" int hmse_stream_piece_sign(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state,
+                                      const uint8_t* rows, uint32_t world, uint32_t rank, const uint64_t* cuts_all, uint64_t* gidx, uint8_t* digests_g,
+                                      uint64_t max_chunks_g, uint64_t* first_occ_g, uint32_t* refcount_g, uint32_t* l3_table, uint64_t l3_slots,
+                                      uint64_t* uniq_all, uint64_t max_unique, uint32_t* sig_all, uint8_t* sig_row, void* ws, size_t ws_bytes, void* stream_) {
+  if (!sb_piece_args_ok(piece_bytes, cap_bytes, piece_bytes ? 1u : 0u, cfg)) return HMSE_EINVAL;
+  if (!data || !state || !rows || !cuts_all || !digests_g || !first_occ_g || !refcount_g || !l3_table || !uniq_all || !sig_all || !sig_row || world == 0 ||
+      world > 256 || rank >= world || (world > 1 && !gidx))
+    return HMSE_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
+  const uint64_t cap = sb_cap_chunks(cap_bytes, cfg);
+  const uint64_t row_bytes = sb::ROW_HDR + 32 * cap;
+  int rc;
+  const uint64_t gthreads = 2ull * world * cap;
+  sb::ingest_rows_kernel<<<dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, stream>>>(rows, row_bytes, world, rank, cap, digests_g, max_chunks_g, gidx, state);
+  if ((rc = hmse_l3_index_update_dyn(digests_g, first_occ_g, refcount_g, l3_table, l3_slots, state + SB_G_OLD, (uint64_t)world * cap, stream)) != HMSE_OK) return rc;
+  sb::select_uniq_kernel<<<dim3(1), dim3(1024), 0, stream>>>(first_occ_g, uniq_all, state, max_unique);
+  if ((rc = hmse_l4_minhash_dyn(data, data_cap, cuts_all, uniq_all, sig_all, state, cap, cfg, w.mh_ws, w.mh_bytes, stream)) != HMSE_OK) return rc;
+  sb::sig_row_kernel<<<dim3(1024), dim3(256), 0, stream>>>(sig_all, state, sb_sig_cap(cap_bytes, cfg), sig_row);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+extern "C" int hmse_stream_piece_bases(uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state, const uint8_t* sig_rows, const hmse_gl4* g,
+                                       const uint64_t* uniq_all, uint32_t* band_keys, int64_t* base_all, void* ws, size_t ws_bytes, void* stream_) {
+  if (hmse_cfg_validate_impl(cfg) != 0 || cap_bytes == 0 || !state || !sig_rows || !gl4_ok(g) || !uniq_all || !band_keys || !base_all) return HMSE_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
+  const uint64_t sig_cap = sb_sig_cap(cap_bytes, cfg);
+  if (g->sig_cap != sig_cap) return HMSE_EINVAL;
+  const uint64_t row_bytes = sb::SIG_HDR + sb::SIG_BYTES * sig_cap;
+  sb::ingest_sig_rows_kernel<<<dim3(2048), dim3(256), 0, stream>>>(sig_rows, row_bytes, g->world, g->rank, sig_cap, g->sig_g, g->g_owner, g->g_local,
+                                                                 g->max_stored_g, g->gstate, state);
+  int rc;
+  if ((rc = hmse_l4_lsh_update_dyn(g->sig_g, g->band_keys_g, g->base_g, g->lsh_tables_g, g->lsh_slots_g, g->gstate, (uint64_t)g->world * sig_cap, cfg, stream)) != HMSE_OK)
+    return rc;
+  sb::resolve_bases_kernel<<<dim3(1), dim3(1024), 0, stream>>>(g->base_g, g->band_keys_g, cfg->bands, g->g_owner, g->g_local, uniq_all, g->world, g->rank,
+                                                              g->ghost_chunk0, g->gstate, state, g->ug, g->base_global, base_all, band_keys, w.sel_ids, w.sel_base,
+                                                              w.n_sel, g->req_counts, g->req_slots);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
+}
+
+extern "C" int hmse_stream_piece_encode_g(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state,
+                                          uint64_t* gstate, const uint64_t* cuts_all, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out,
+                                          uint64_t out_cap, void* ws, size_t ws_bytes, void* stream_) {
+  if (!sb_piece_args_ok(piece_bytes, cap_bytes, piece_bytes ? 1u : 0u, cfg)) return HMSE_EINVAL;
+  if (!data || !state || !gstate || !cuts_all || !kind_all || !stream_off_all || !out) return HMSE_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)hipGetLastError();
+  const sb::Ws w = sb_carve(ws, cap_bytes, cfg);
+  if (!ws || ws_bytes < w.total) return HMSE_ENOSPC;
+  const uint64_t cap = sb_cap_chunks(cap_bytes, cfg);
+  int rc;
+  if ((rc = hmse_l1_deflate_dyn(data, data_cap, cuts_all, w.sel_ids, w.sel_base, w.n_sel, cap, state + SB_S_OLD, cfg, out, out_cap, w.out_off, w.kind,
+                                w.dfl_status, w.dfl_ws, w.dfl_bytes, stream)) != HMSE_OK) return rc;
+  uint32_t ab = (uint32_t)((cap + 255) / 256); if (ab > 1024) ab = 1024;
+  sb::commit_kernel<<<dim3(ab), dim3(256), 0, stream>>>(w.kind, w.out_off, cap, kind_all, stream_off_all, w.dfl_status, state);
+  sb::advance_g_kernel<<<dim3(1), dim3(1), 0, stream>>>(gstate, state);
+  sb::advance_kernel<<<dim3(1), dim3(1), 0, stream>>>(state, piece_bytes);
+  HMSE_LAUNCH_CHECK();
+  return HMSE_OK;
 }

@@ -446,3 +446,49 @@ def stream_piece_encode(data: torch.Tensor, piece_bytes: int, cap_bytes: int, cf
                                                 _ptr(band_keys), _ptr(base_all), _ptr(lsh_tables), lsh_tables.shape[1], _ptr(kind_all),
                                                 _ptr(stream_off_all), _ptr(out), out.numel(), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "hmse_stream_piece_encode")
+
+
+# ---- global L4 of a multi-rank stream as captured phases (include/hmse.h: hmse_gl4) ---------------------------------------------
+def stream_sig_cap(cap_bytes: int, cfg: IngestConfig) -> int:
+    c = cfg.to_c()
+    return int(_lib.hip_lib().hmse_stream_sig_cap(int(cap_bytes), C.byref(c)))
+
+
+def stream_sig_row_bytes(cap_bytes: int, cfg: IngestConfig) -> int:
+    c = cfg.to_c()
+    return int(_lib.hip_lib().hmse_stream_sig_row_bytes(int(cap_bytes), C.byref(c)))
+
+
+def stream_piece_sign(data, piece_bytes, cap_bytes, cfg, state, rows, world, rank, cuts_all, gidx, digests_g, max_chunks_g, first_occ_g, refcount_g,
+                      l3_table, uniq_all, max_unique, sig_all, sig_row, ws) -> None:
+    """hmse_stream_piece_sign: gathered digest rows -> global index -> this rank's new stored chunks -> MinHash -> its signature row."""
+    for t, nm in ((data, "data"), (state, "state"), (rows, "rows"), (cuts_all, "cuts"), (digests_g, "digests"), (first_occ_g, "first_occ"),
+                  (refcount_g, "refcount"), (l3_table, "l3_table"), (uniq_all, "uniq"), (sig_all, "sig"), (sig_row, "sig_row"), (ws, "ws")):
+        _require_gpu(t, nm)
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_piece_sign(_ptr(data), data.numel(), int(piece_bytes), int(cap_bytes), C.byref(c), _ptr(state), _ptr(rows), int(world),
+                                              int(rank), _ptr(cuts_all), _ptr(gidx), _ptr(digests_g), int(max_chunks_g), _ptr(first_occ_g), _ptr(refcount_g),
+                                              _ptr(l3_table), l3_table.numel(), _ptr(uniq_all), int(max_unique), _ptr(sig_all), _ptr(sig_row),
+                                              ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_piece_sign")
+
+
+def stream_piece_bases(cap_bytes, cfg, state, sig_rows, gl4, uniq_all, band_keys, base_all, ws) -> None:
+    """hmse_stream_piece_bases: gathered signature rows -> global band tables -> dictionaries of this rank's new stored chunks + requests.
+    `gl4`: a _lib.HmseGl4 (kept alive by the caller together with the tensors it points to)."""
+    for t, nm in ((state, "state"), (sig_rows, "sig_rows"), (uniq_all, "uniq"), (band_keys, "band_keys"), (base_all, "base"), (ws, "ws")):
+        _require_gpu(t, nm)
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_piece_bases(int(cap_bytes), C.byref(c), _ptr(state), _ptr(sig_rows), C.byref(gl4), _ptr(uniq_all), _ptr(band_keys),
+                                               _ptr(base_all), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_piece_bases")
+
+
+def stream_piece_encode_g(data, piece_bytes, cap_bytes, cfg, state, gstate, cuts_all, kind_all, stream_off_all, out, ws) -> None:
+    """hmse_stream_piece_encode_g: DEFLATE of the new stored chunks with the dictionaries resolved by stream_piece_bases, tails, states advanced."""
+    for t, nm in ((data, "data"), (state, "state"), (gstate, "gstate"), (cuts_all, "cuts"), (kind_all, "kind"), (stream_off_all, "stream_off"), (out, "out"), (ws, "ws")):
+        _require_gpu(t, nm)
+    c = cfg.to_c()
+    rc = _lib.hip_lib().hmse_stream_piece_encode_g(_ptr(data), data.numel(), int(piece_bytes), int(cap_bytes), C.byref(c), _ptr(state), _ptr(gstate),
+                                                  _ptr(cuts_all), _ptr(kind_all), _ptr(stream_off_all), _ptr(out), out.numel(), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "hmse_stream_piece_encode_g")

@@ -336,6 +336,55 @@ int hmse_stream_piece_encode(uint8_t* data, uint64_t data_cap, uint64_t piece_by
                              uint8_t* out, uint64_t out_cap, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * Global L4 for a multi-rank stream as captured phases (round 4; SURVEY.md §8f-3: "cross-GPU base-chunk fetch over xGMI P2P for global L4
+ * (config 5)"; the reference keeps ONE set of band tables, README.md:1375-1383).  The stored chunks of all ranks are numbered in global
+ * stored order (batch, rank, local); every rank holds the same signature array, band tables and owner map of that numbering and therefore
+ * finds, for each of its chunks, the dictionary that ONE rank ingesting the whole stream would find.  Phase B of a batch becomes three
+ * enqueue-only calls around two more exchange steps:
+ *   hmse_stream_piece_sign      rows of all ranks (as for hmse_stream_piece_encode) -> global index -> this rank's new stored chunks ->
+ *                               MinHash -> sig_row {u64 count, u64 first local stored slot, 16 B pad, sig_cap x 512 B}
+ *   -- all-gather of the signature rows (fixed size: hmse_stream_sig_row_bytes) --
+ *   hmse_stream_piece_bases     sig rows -> global signature array + owner map -> global band tables -> for every new stored chunk of
+ *                               this rank its dictionary: a chunk of this rank, or a REMOTE one -> request (owner, owner's stored slot);
+ *                               g->req_counts[q] requests to rank q ([world] = total), g->req_slots grouped by owner
+ *   -- the requested chunks are fetched (all-to-all; the caller writes the bytes behind its data and their bounds into
+ *      cuts_all[g->ghost_chunk0 ..]: request j is chunk ghost_chunk0 + j) --
+ *   hmse_stream_piece_encode_g  DEFLATE of the new stored chunks with those dictionaries, tails, both state blocks advanced
+ * gstate: DEVICE u64[16], word [3] = stored chunks of ALL ranks before this batch, [4] = of this batch (out), [10] = global stored index
+ * of this rank's first new chunk (out).  Status bits as hmse_stream_batch, plus bit7: more new stored chunks than a signature row holds.
+ * All arrays are the caller's; sizes in the struct.
+ */
+typedef struct hmse_gl4 {
+  uint32_t struct_size, world, rank, reserved;
+  uint64_t sig_cap;        /* hmse_stream_sig_cap(cap_bytes, cfg) */
+  uint64_t max_stored_g;   /* capacity of the global stored-chunk arrays */
+  uint64_t* gstate;
+  uint32_t* sig_g;         /* [max_stored_g][128] */
+  uint32_t* band_keys_g;   /* [max_stored_g][bands] */
+  int64_t*  base_g;        /* [max_stored_g] global stored index of the dictionary, -1 none */
+  uint32_t* lsh_tables_g;  /* [bands][lsh_slots_g], cleared by hmse_l4_lsh_update(n_old = n_new = 0) */
+  uint64_t  lsh_slots_g;
+  uint32_t* g_owner;       /* [max_stored_g] owning rank */
+  uint64_t* g_local;       /* [max_stored_g] the owner's stored slot */
+  uint64_t* ug;            /* [max_unique] this rank's stored chunks: global stored index (out, appended) */
+  int64_t*  base_global;   /* [max_unique] this rank's stored chunks: base_g (out, appended) */
+  uint64_t* req_counts;    /* DEVICE u64[world + 1] (out) */
+  uint64_t* req_slots;     /* DEVICE u64[cap chunks of a piece] (out) */
+  uint64_t  ghost_chunk0;  /* chunk id of the batch's first fetched dictionary */
+} hmse_gl4;
+uint64_t hmse_stream_sig_cap(uint64_t cap_bytes, const hmse_cfg* cfg);
+uint64_t hmse_stream_sig_row_bytes(uint64_t cap_bytes, const hmse_cfg* cfg);
+int hmse_stream_piece_sign(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state,
+                           const uint8_t* rows, uint32_t world, uint32_t rank, const uint64_t* cuts_all, uint64_t* gidx, uint8_t* digests_g,
+                           uint64_t max_chunks_g, uint64_t* first_occ_g, uint32_t* refcount_g, uint32_t* l3_table, uint64_t l3_slots,
+                           uint64_t* uniq_all, uint64_t max_unique, uint32_t* sig_all, uint8_t* sig_row, void* ws, size_t ws_bytes, void* stream);
+int hmse_stream_piece_bases(uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state, const uint8_t* sig_rows, const hmse_gl4* g,
+                            const uint64_t* uniq_all, uint32_t* band_keys, int64_t* base_all, void* ws, size_t ws_bytes, void* stream);
+int hmse_stream_piece_encode_g(uint8_t* data, uint64_t data_cap, uint64_t piece_bytes, uint64_t cap_bytes, const hmse_cfg* cfg, uint64_t* state,
+                               uint64_t* gstate, const uint64_t* cuts_all, uint8_t* kind_all, uint64_t* stream_off_all, uint8_t* out,
+                               uint64_t out_cap, void* ws, size_t ws_bytes, void* stream);
+
+/*
  * Chunk manifest — the packed on-disk records, written on the GPU (README.md:1263-1270 ChunkIndex 40 B, 2182-2189
  * DeltaChunk 8-byte header + delta data, 1312 pointer 8 B, 1448 per-chunk map, 1635-1669 chunk types).  Replaces the
  * reference's per-chunk "write chunk, insert (sha -> lba, len)" / "pointer record, refcount++" steps of the batch loop

@@ -31,12 +31,15 @@ def main():
     ap.add_argument("--verify", action="store_true", help="decode this rank's stored records and re-check their SHA-256 (outside the clock)")
     ap.add_argument("--global-l4", action="store_true", help="base selection over all ranks (stream_dist.GlobalL4StreamIngest: signatures all-gathered "
                     "per batch, remote dictionaries fetched by all-to-alls; enqueued stage by stage, no hipGraph); needs --gpus > 1")
+    ap.add_argument("--global-l4-graph", action="store_true", help="global L4 with every phase hipGraph-captured (stream_gl4.GraphGlobalL4StreamIngest: "
+                    "fixed-size digest and signature rows all-gathered, only the remote-dictionary fetch eager); also at --gpus 1")
+    ap.add_argument("--always-exchange", action="store_true", help="--gpus 1: run the per-batch collectives on RCCL anyway (what one GPU can show of their cost)")
     a = ap.parse_args()
     json_fd = os.dup(1)
     os.dup2(2, 1)
     import torch
     import torch.distributed as dist
-    from hmse_amd import IngestConfig, corpus, ingest, read, stream_dist
+    from hmse_amd import IngestConfig, corpus, ingest, read, stream_dist, stream_gl4
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -66,8 +69,12 @@ def main():
     t_gen = time.time() - t0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or a.always_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "RANK" not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo" if rehearse else "nccl", **({} if rehearse else {"device_id": dev}))
 
     def barrier():
@@ -79,8 +86,9 @@ def main():
     # warm-up outside the clock: module load, kernel attributes, allocator, the collective's first call
     wp = min(64 << 20, piece)
     wn = max(1, min(4, host.numel() // wp))
-    mk = (lambda cap, pc: stream_dist.GlobalL4StreamIngest(cfg, cap, pc, dev, world, rank)) if a.global_l4 else \
-        (lambda cap, pc: stream_dist.DistStreamIngest(cfg, cap, pc, dev, world, rank, graph=not a.no_graph))
+    mk = (lambda cap, pc: stream_gl4.GraphGlobalL4StreamIngest(cfg, cap, pc, dev, world, rank, graph=not a.no_graph, always_exchange=a.always_exchange)) if a.global_l4_graph else \
+        (lambda cap, pc: stream_dist.GlobalL4StreamIngest(cfg, cap, pc, dev, world, rank)) if a.global_l4 else \
+        (lambda cap, pc: stream_dist.DistStreamIngest(cfg, cap, pc, dev, world, rank, graph=not a.no_graph, always_exchange=a.always_exchange))
     w = mk(wn * wp, wp)
     for k in range(wn):
         w.push(host[k * wp: (k + 1) * wp])
@@ -99,7 +107,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = res.stats
-    verified = read.verify_stored(res) if a.verify and not a.global_l4 else None    # (global L4: dictionaries on other ranks — tests/ decode all ranks together)
+    verified = read.verify_stored(res) if a.verify and not (a.global_l4 or (a.global_l4_graph and world > 1)) else None    # (global L4: dictionaries on other ranks — tests/ decode all ranks together)
     stats = [st]
     if world > 1:
         stats = [None] * world
@@ -111,17 +119,18 @@ def main():
                "config": {"workload": f"{total / 1e9:.2f} GB mixed corpora streamed in {n_batches} global batches of {world} x {piece >> 20} MiB pieces, full L1-L4, "
                                       f"{'hipGraph-captured' if not (a.no_graph or a.global_l4) else 'eagerly enqueued'} per-batch chain, host->HBM copies included",
                           "collective": ("all_gather(digests) + all_gather(signatures) + 3 all_to_all (remote dictionaries) per batch over " if a.global_l4 else "all_gather(exchange rows) per batch over ") + ("gloo — REHEARSAL, all ranks on one GPU, not a measurement" if rehearse else "RCCL") if world > 1 else "none",
-                          "global_chunk_order": "(batch, rank, local)", "l4_scope": "global" if a.global_l4 else "rank-local"},
+                          "global_chunk_order": "(batch, rank, local)", "l4_scope": "global, captured phases (stream_gl4)" if a.global_l4_graph else "global" if a.global_l4 else "rank-local",
+                          "collectives_at_world_1": "run on RCCL anyway (--always-exchange)" if (world == 1 and a.always_exchange) else None},
                "ms_total": round(dt * 1e3, 1), "ms_per_batch": round(dt * 1e3 / n_batches, 2), "cf": round(tot["cf"], 4), "cf_payload": round(tot["cf_payload"], 4),
                "chunks": tot["chunks"], "unique_chunk_ratio": round(tot["unique_chunk_ratio"], 4), "delta_rate": round(tot["delta_rate"], 4),
                "n_global_chunks": res.n_global, "corpus_gen_s": round(t_gen, 1), "hbm_in_use_GiB_rank0": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
         if verified is not None:
             out["sha256_verified_records_rank0"] = verified
-        if a.global_l4:
+        if a.global_l4 or a.global_l4_graph:
             out["remote_dictionaries_rank0"] = s.remote_dictionaries
             out["ghost_bytes_fetched_rank0"] = s.ghost_bytes_fetched
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if world > 1 or a.always_exchange:
         dist.barrier()
         dist.destroy_process_group()
 
