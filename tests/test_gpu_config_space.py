@@ -89,3 +89,36 @@ def test_l2_cuts_bit_exact_over_norm_levels(norm_level, orc, dev):
             assert got.shape == want.shape and np.array_equal(got, want), (norm_level, cfg.avg_size, cfg.seg_size, data.size)
     sizes = np.diff(orc.cdc(inputs[0], ocfg(orc, IngestConfig(norm_level=norm_level))))
     assert sizes.max() <= 32768 and sizes[:-1].min() >= 2048
+
+
+@pytest.mark.parametrize("kw", [dict(seed_base=1), dict(level=6), dict(level=1, seed_base=1), dict(delta_max_ratio_pct=20)],
+                         ids=["seeds-1..128", "level-6", "level-1+seeds", "20pct-gate"])
+def test_full_pipeline_at_the_reference_s_literal_constants(kw, orc, dev):
+    """The reference's own constants, end to end: 1 / 4 / 16 KiB chunks (`README.md:2444-2446`), MinHash seeds 1..128 as the validation plan
+    words them (`VALIDATION_METHODS.md:122`; the code's 0..127 is the default), lower DEFLATE levels, the literal 20 % delta gate
+    (`README.md:1328, 2175`) — every output of `ingest_shard` equals the oracle pipeline with the same configuration, and the stream of
+    batches (device-count chain) gives the same records."""
+    import os, sys, torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import variants_dataset
+    from test_gpu_ingest import oracle_pipeline
+    from hmse_amd import IngestConfig, corpus, ingest, stream
+    cfg = IngestConfig.reference_preset().with_(seg_size=1 << 20, **kw)
+    data = np.concatenate([variants_dataset(corpus.wiki_synth(2 << 20, seed=42)), corpus.wiki_synth(2 << 20, seed=43)])
+    data = data[: data.size // (1 << 20) * (1 << 20)]
+    res = ingest.ingest_shard(torch.from_numpy(data).to(dev), cfg)
+    _, (o,) = oracle_pipeline(orc, data, cfg)
+    for name, got, want in (("cuts", res.cuts.cpu().numpy().astype(np.uint64), o["cuts"]), ("digests", res.digests.cpu().numpy(), o["dg"]),
+                            ("first_occ", res.first_occ.cpu().numpy().astype(np.uint64), o["fo"]), ("uniq", res.uniq_ids.cpu().numpy().astype(np.uint64), o["uniq"]),
+                            ("sig", res.sig.cpu().numpy().view(np.uint32), o["sig"]), ("base", res.base.cpu().numpy(), o["base"]),
+                            ("kind", res.kind.cpu().numpy(), o["kind"]), ("off", res.stream_off.cpu().numpy().astype(np.uint64), o["off"]),
+                            ("streams", res.streams.cpu().numpy(), o["out"])):
+        assert got.shape == want.shape and np.array_equal(got, want), (kw, name)
+    sizes = np.diff(o["cuts"].astype(np.int64))
+    assert sizes.max() <= 16384 and sizes.mean() < 6500 and res.stats["delta"] > 5
+    s = stream.StreamIngest(cfg, data.size, dev, graph=True)
+    for a in range(0, data.size, 2 << 20):
+        s.push(torch.from_numpy(data[a: a + (2 << 20)].copy()))
+    r2 = s.finish()
+    for name in ("cuts", "digests", "first_occ", "uniq_ids", "sig", "base", "kind", "stream_off", "streams"):
+        assert torch.equal(getattr(r2, name), getattr(res, name)), (kw, name)
