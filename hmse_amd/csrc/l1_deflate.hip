@@ -537,7 +537,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     PF_STAGE(0);
     // ---- phase 1-2: bucket histogram + exclusive scan -> bucket starts --------------------------
     const uint32_t nh = T >= 4 ? T - 3 : 0;
-    for (uint32_t q = t; q < nh; q += NT) cur_inc(cur, hash4(ld32(W + q)));
+    // (four consecutive positions per lane from two ALIGNED dwords: a 4-byte LDS read at an arbitrary byte address is replayed lane by lane,
+    // ~64 clocks per wave-instruction — §6.2 — and this loop, like the scatter below, read every position that way until round 4)
+    for (uint32_t q4 = t * 4u; q4 < nh; q4 += NT * 4u) {
+      const uint32_t d0 = *(const uint32_t*)(W + q4), d1 = *(const uint32_t*)(W + q4 + 4u);
+      cur_inc(cur, hash4(d0));
+      if (q4 + 1u < nh) cur_inc(cur, hash4(alignb(d1, d0, 1u)));
+      if (q4 + 2u < nh) cur_inc(cur, hash4(alignb(d1, d0, 2u)));
+      if (q4 + 3u < nh) cur_inc(cur, hash4(alignb(d1, d0, 3u)));
+    }
     __syncthreads();
     {
       constexpr int PERW = NBK / 2 / NT > 0 ? NBK / 2 / NT : 1;  // packed words per thread
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // (filter byte of a position: low nibble of its byte 4 | four more bits of its hash product, see the matcher's `rejects`)
       uint32_t q = t, h = 0, before = 0, hx = 0;
       bool act = q < nh;
-      if (act) { hx = ld32(W + q) * 0x9E3779B1u; h = hx >> (32 - HB); before = cur_get(cur, h); }
+      if (act) { hx = ld32a(W, q) * 0x9E3779B1u; h = hx >> (32 - HB); before = cur_get(cur, h); }
       __syncthreads();
       for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
         if (act) S[cur_inc(cur, h)] = (uint16_t)q;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         const uint32_t qn = q0 + NT + t;
         const bool actn = qn < nh;
         uint32_t hn = 0, beforen = 0, hxn = 0;
-        if (actn) { hxn = ld32(W + qn) * 0x9E3779B1u; hn = hxn >> (32 - HB); beforen = cur_get(cur, hn); }
+        if (actn) { hxn = ld32a(W, qn) * 0x9E3779B1u; hn = hxn >> (32 - HB); beforen = cur_get(cur, hn); }
         __syncthreads();
         if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = (uint8_t)((W[q + 4] & 0x0Fu) | ((hx >> 12) & 0xF0u)); }
         q = qn; act = actn; h = hn; before = beforen; hx = hxn;

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
     __syncthreads();
     const bool ins = s_ins != 0;
     // insert R of every shingle of this pass
-    const uint8_t* src = data + start + sub0;
-    for (uint32_t p = t; p < (V == 3 ? 0u : cnt); p += NT) {
-      const uint32_t R = murmur_R(load_u32_unaligned(src + p));
+    // Four consecutive shingles per lane from three ALIGNED, coalesced dword loads (round 4): a 4-byte load at a byte-granular address per
+    // lane — what this loop did, one per shingle — is handled lane by lane by the memory pipeline; the aligned form is a quarter of the load
+    // instructions, each a plain coalesced 256-byte read.  (Shingle k of the chunk = bytes [k, k + 4): the same values, only fetched differently.)
+    auto set_insert = [&](uint32_t x) {
+      const uint32_t R = murmur_R(x);
       if (R == MH_EMPTY) {
         s_flag = 1;
       } else {
@@ -133,6 +135,27 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
           const uint32_t old = atomicCAS(&s_tab[slot], MH_EMPTY, R);
           if (old == MH_EMPTY || old == R) break;
           slot = (slot + 1) & (MH_SLOTS - 1);
+        }
+      }
+    };
+    {
+      const uint64_t b0 = start + sub0;                      // byte offset of this pass's first shingle
+      const uint32_t sh = (uint32_t)(b0 & 3u);
+      const uint8_t* const abase = data + (b0 - sh);         // 4-byte aligned (data comes from the allocator: 256-byte aligned; offsets are bytes)
+      const bool base_aligned = (((uintptr_t)data) & 3u) == 0;
+      for (uint32_t p4 = t * 4u; p4 < (V == 3 ? 0u : cnt); p4 += NT * 4u) {
+        const uint64_t a = (b0 - sh) + p4;
+        if (base_aligned && a + 12 <= n) {
+          const uint32_t* w = (const uint32_t*)(abase + p4);
+          const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+          const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh), y0 = __builtin_amdgcn_alignbyte(w2, w1, sh);   // bytes [p4, p4 + 4), [p4 + 4, p4 + 8)
+          set_insert(x0);
+          if (p4 + 1u < cnt) set_insert(__builtin_amdgcn_alignbyte(y0, x0, 1u));
+          if (p4 + 2u < cnt) set_insert(__builtin_amdgcn_alignbyte(y0, x0, 2u));
+          if (p4 + 3u < cnt) set_insert(__builtin_amdgcn_alignbyte(y0, x0, 3u));
+        } else {
+          const uint8_t* src = data + b0;
+          for (uint32_t k = 0; k < 4u && p4 + k < cnt; k++) set_insert(load_u32_unaligned(src + p4 + k));
         }
       }
     }
