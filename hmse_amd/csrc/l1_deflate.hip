@@ -518,9 +518,15 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       if (i + 16 <= Dl) { const uint4 v = load_u4_unaligned(dsrc + i); __builtin_memcpy(W + i, &v, 16); }
       else for (uint32_t b = i; b < Dl; b++) W[b] = dsrc[b];
     }
-    for (uint32_t i = t * 16; i < L; i += NT * 16) {
-      if (i + 16 <= L) { const uint4 v = load_u4_unaligned(csrc + i); __builtin_memcpy(W + Dl + i, &v, 16); }
-      else for (uint32_t b = i; b < L; b++) W[Dl + b] = csrc[b];
+    {
+      // the chunk behind the dictionary: whole 16-byte LDS slots are written ALIGNED (the global side takes the misalignment: Dl is any
+      // byte count, and a 16-byte LDS store off its alignment is replayed lane by lane), the edges byte by byte
+      const uint32_t a0 = (Dl + 15u) & ~15u, a1 = T & ~15u;      // aligned slots [a0, a1) lie inside [Dl, T)
+      if (a0 < a1) {
+        for (uint32_t o = a0 + t * 16; o < a1; o += NT * 16) { const uint4 v = load_u4_unaligned(csrc + (o - Dl)); *(uint4*)(W + o) = v; }
+        if (t < a0 - Dl) W[Dl + t] = csrc[t];
+        if (t < T - a1) W[a1 + t] = csrc[a1 - Dl + t];
+      } else if (t < L) W[Dl + t] = csrc[t];                     // (fewer than 31 bytes)
     }
     if (t < 64) W[T + t] = 0;
     for (uint32_t i = t; i < NBK / 2; i += NT) cur[i] = 0;
