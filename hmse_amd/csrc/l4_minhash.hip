@@ -162,12 +162,18 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
     __syncthreads();
     // in-place compaction of this wave's part (write index never passes the read index)
     uint32_t wr = 0;
-    for (uint32_t i = 0; i < (uint32_t)PART; i += 64) {
-      const uint32_t v = q[i + lane];
-      const bool valid = v != MH_EMPTY;
-      const uint64_t m = __ballot(valid);
-      if (valid) q[wr + (uint32_t)__builtin_popcountll(m & lanemask_lt())] = v;
-      wr += (uint32_t)__builtin_popcountll(m);
+    static_assert(PART % 256 == 0, "the compaction reads four 64-entry rows per round trip");
+    for (uint32_t i = 0; i < (uint32_t)PART; i += 256) {   // (four independent reads in flight, then the four appends: all of a group's reads precede its writes)
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = q[i + 64 * u + lane];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool valid = v[u] != MH_EMPTY;
+        const uint64_t m = __ballot(valid);
+        if (valid) q[wr + mbcnt64(m)] = v[u];
+        wr += (uint32_t)__builtin_popcountll(m);
+      }
     }
     // ---- memo lookups: every distinct shingle of this wavefront's part; what the table cannot answer goes to the top of
     // the part (the todo list), which the tail loop below then streams instead of the whole part
