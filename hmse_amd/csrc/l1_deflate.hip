@@ -729,18 +729,20 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
 #else
     constexpr bool ORD = LDSM;
 #endif
-    uint16_t* const ordA = (uint16_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride + 98304u);
-    uint16_t* const ordB = ordA + 32768;
+    uint32_t* const ord = (uint32_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride + 98304u);
     if constexpr (ORD) {
       // Two passes over this wavefront's ranks (64 per step, a step every NT ranks; ITER steps at most): the first classifies — all
       // its LDS reads are independent and issue back to back — and counts per class in scalars; ONE LDS atomic per wavefront and class
-      // reserves the list slots; the second pass (no memory reads: the classes sit packed in registers, 3 bits each) stores the ranks.
+      // reserves the list slots, and a barrier later the class totals place the four lists one behind the other; the second pass (no
+      // memory reads: what it stores sits packed in registers, 10 bits per rank) writes the list.
       // (A first version with one atomic round trip per step cost 5.5 % of a job: seven dependent LDS chains per wavefront.)
+      // A list entry carries what the matcher's pull would otherwise compute again for every position, ~15 vector instructions issued
+      // for the whole wavefront in nearly every trip: rank | candidate count << 15 | the four hash-product bits of the filter byte << 21.
       constexpr int ITER = (TCAP + NT - 1) / NT;
       const uint32_t wv = uni32(wave);   // (scalar control: the cross-lane reads below never run under a narrowed EXEC)
-      uint32_t pk[(ITER + 9) / 10];
+      uint32_t pk[(ITER + 2) / 3];
 #pragma unroll
-      for (int w = 0; w < (ITER + 9) / 10; w++) pk[w] = 0;
+      for (int w = 0; w < (ITER + 2) / 3; w++) pk[w] = 0;
       uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
       // (branch-free and staged — all S reads, then all window reads, then all cursor reads: three LDS round trips per wavefront
       // instead of three per step; as nested ifs the compiler serialised the steps, 27 dependent round trips in class S)
@@ -753,26 +755,26 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
 #pragma unroll
           for (int u = 0; u < G; u++) if (g + u < ITER) { const uint32_t r = (wv << 6) + (uint32_t)(g + u) * NT + lane; pv[u] = S[r < last ? r : last]; }
 #pragma unroll
-          for (int u = 0; u < G; u++) if (g + u < ITER) hv[u] = hash4(ld32a(W, pv[u]));
+          for (int u = 0; u < G; u++) if (g + u < ITER) hv[u] = ld32a(W, pv[u]) * 0x9E3779B1u;   // (the hash product: bucket = its top HB bits)
 #pragma unroll
-          for (int u = 0; u < G; u++) if (g + u < ITER) lv[u] = cur_get(cur, (hv[u] - 1u) & (uint32_t)(NBK - 1));   // (= end of the bucket before; unused for bucket 0)
+          for (int u = 0; u < G; u++) if (g + u < ITER) lv[u] = cur_get(cur, ((hv[u] >> (32 - HB)) - 1u) & (uint32_t)(NBK - 1));   // (= end of the bucket before; unused for bucket 0)
 #pragma unroll
           for (int u = 0; u < G; u++) if (g + u < ITER) {
             const int it = g + u;
             const uint32_t r = (wv << 6) + (uint32_t)it * NT + lane;
-            uint32_t km = r - (hv[u] ? lv[u] : 0u);
+            uint32_t km = r - ((hv[u] >> (32 - HB)) ? lv[u] : 0u);
             km = km < a.depth ? km : a.depth;
-            uint32_t cls = km >= 24u ? 0u : km >= 12u ? 1u : km >= 4u ? 2u : km >= 1u ? 3u : 4u;
-            cls = r < nh ? cls : 4u;
+            km = km < 63u ? km : 63u;   // (6 bits in the entry; a deeper configuration recomputes the count at the pull)
+            km = r < nh ? km : 0u;
             if constexpr (DICT) {
               const uint32_t pp = pv[u];
               uint32_t bq;
               const uint32_t bm = pp >= Dl ? hint_of(pp, (T - pp) < MAXM ? (T - pp) : MAXM, bq) : 16u;
-              cls = bm >= 16u ? 4u : cls;   // a dictionary position (a candidate only) or a hinted chunk position: no walk
+              km = bm >= 16u ? 0u : km;   // a dictionary position (a candidate only) or a hinted chunk position: no walk
             }
-            pk[it / 10] |= cls << (3 * (it % 10));
-            n0 += (uint32_t)__builtin_popcountll(__ballot(cls == 0u)); n1 += (uint32_t)__builtin_popcountll(__ballot(cls == 1u));
-            n2 += (uint32_t)__builtin_popcountll(__ballot(cls == 2u)); n3 += (uint32_t)__builtin_popcountll(__ballot(cls == 3u));
+            pk[it / 3] |= (km | ((hv[u] >> 10) & 0x3C0u)) << (10 * (it % 3));   // km (6 bits) | bits 16..19 of the hash product << 6
+            n0 += (uint32_t)__builtin_popcountll(__ballot(km >= 24u)); n1 += (uint32_t)__builtin_popcountll(__ballot(km >= 12u && km < 24u));
+            n2 += (uint32_t)__builtin_popcountll(__ballot(km >= 4u && km < 12u)); n3 += (uint32_t)__builtin_popcountll(__ballot(km >= 1u && km < 4u));
           }
         }
       }
@@ -780,16 +782,21 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       if (lane < 4u) bv = atomicAdd(&sm.ocnt[lane], lane == 0u ? n0 : lane == 1u ? n1 : lane == 2u ? n2 : n3);
       uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 1),
                b2 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)bv, 3);
+      __syncthreads();   // every wavefront's counts are in: class totals -> where each class's list starts
+      {
+        const uint32_t c0 = uni32(sm.ocnt[0]), c1 = uni32(sm.ocnt[1]), c2 = uni32(sm.ocnt[2]);
+        b1 += c0; b2 += c0 + c1; b3 += c0 + c1 + c2;
+      }
 #pragma unroll
       for (int it = 0; it < ITER; it++) {
         const uint32_t r0 = (wv << 6) + (uint32_t)it * NT;
         if (r0 < nh) {
-          const uint32_t cls = (pk[it / 10] >> (3 * (it % 10))) & 7u;
-          const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u), m3 = __ballot(cls == 3u);
-          if (cls < 4u) {
-            const uint64_t mm = cls == 0u ? m0 : cls == 1u ? m1 : cls == 2u ? m2 : m3;
-            const uint32_t pos = (cls == 0u ? b0 : cls == 1u ? b1 : cls == 2u ? b2 : b3) + mbcnt64(mm);
-            (cls < 2u ? ordA : ordB)[(cls & 1u) ? 32767u - pos : pos] = (uint16_t)(r0 + lane);
+          const uint32_t kv = (pk[it / 3] >> (10 * (it % 3))) & 0x3FFu, km = kv & 63u;
+          const uint64_t m0 = __ballot(km >= 24u), m1 = __ballot(km >= 12u && km < 24u), m2 = __ballot(km >= 4u && km < 12u), m3 = __ballot(km >= 1u && km < 4u);
+          if (km != 0u) {
+            const uint64_t mm = km >= 24u ? m0 : km >= 12u ? m1 : km >= 4u ? m2 : m3;
+            const uint32_t pos = (km >= 24u ? b0 : km >= 12u ? b1 : km >= 4u ? b2 : b3) + mbcnt64(mm);
+            ord[pos] = (r0 + lane) | (kv << 15);
           }
           b0 += (uint32_t)__builtin_popcountll(m0); b1 += (uint32_t)__builtin_popcountll(m1);
           b2 += (uint32_t)__builtin_popcountll(m2); b3 += (uint32_t)__builtin_popcountll(m3);
@@ -827,8 +834,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       uint64_t wq_mask = 0; uint32_t wq_base = 0; bool wq_done = false;
       const uint32_t nh_s = uni32(nh);
       // plain jobs: ranks per class -> ends of the four list segments in hand-out order
-      const uint32_t oc0 = ORD ? uni32(sm.ocnt[0]) : 0u, oe1 = ORD ? oc0 + uni32(sm.ocnt[1]) : 0u, oe2 = ORD ? oe1 + uni32(sm.ocnt[2]) : 0u,
-                     n_ord = ORD ? oe2 + uni32(sm.ocnt[3]) : nh_s;
+      const uint32_t n_ord = ORD ? uni32(sm.ocnt[0]) + uni32(sm.ocnt[1]) + uni32(sm.ocnt[2]) + uni32(sm.ocnt[3]) : nh_s;
       uint8_t* const wtab = sm.wtab + (wave << 6);
       // state of a freshly pulled position (rank ii holds chunk position pp)
       auto begin_walk = [&](uint32_t ii, uint32_t pp) {
@@ -852,6 +858,29 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         if (DICT && t == 0) stamp_acc[7]++;  // lane 0's walked positions
 #endif
         if (kmax != 0) st = PROBE;  // (else: first of its bucket, no match — the lane pulls again)
+      };
+      // the same from a hand-out list entry (rank | candidate count << 15 | filter bits << 21; a listed rank has a candidate, so i >= 1)
+      auto begin_walk_listed = [&](uint32_t e) {
+        i = e & 0x7FFFu; kmax = (e >> 15) & 63u;
+        p = S[i];
+        qn = S[i - 1];
+        kn = NOK ? (uint32_t)W[qn + 4] : (uint32_t)K[i - 1];
+#ifndef HMSE_NO_PROBE16
+        { uint64_t pp__[2]; ldNa<2>(W, p, pp__); pw0 = (uint32_t)pp__[0]; pw1 = (uint32_t)(pp__[0] >> 32); pw2 = (uint32_t)pp__[1]; pw3 = (uint32_t)(pp__[1] >> 32); }
+#else
+        ld64a(W, p, pw0, pw1);
+#endif
+        pkey = (pw1 & 0x0Fu) | ((e >> 17) & 0xF0u);
+        if (kmax == 63u) {   // (the entry's count saturates at 63: a deeper configuration recomputes it — no lane comes here at depth <= 62)
+          const uint32_t h = hash4(pw0), lo = h ? cur_get(cur, h - 1) : 0u;
+          kmax = i - lo < a.depth ? i - lo : a.depth;
+        }
+        maxlen = (T - p) < MAXM ? (T - p) : MAXM;
+        best = MINM - 1; bd = 0; probe = pw0; kk = 1;
+#ifdef HMSE_DFL_STAMPS
+        if (DICT && t == 0) stamp_acc[7]++;
+#endif
+        st = PROBE;
       };
       // every wavefront leaves this loop: by running out of work, or — never observed on a correct build — by using up a trip
       // budget no legal walk can reach (status bit 4: the job's record is then garbage and the call reports it)
@@ -923,12 +952,8 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           if (st == FETCH) {
             const uint32_t f = base + mbcnt64(need);
             if (f >= n_ord) st = DONE;
-            else if constexpr (ORD) {
-              const uint16_t* const src = f < oe1 ? ordA : ordB;
-              const uint32_t idx = f < oc0 ? f : f < oe1 ? 32767u - (f - oc0) : f < oe2 ? f - oe1 : 32767u - (f - oe2);
-              const uint32_t ii = src[idx];
-              begin_walk(ii, (uint32_t)S[ii]);
-            } else begin_walk(f, (uint32_t)S[f]);
+            else if constexpr (ORD) begin_walk_listed(ord[f]);
+            else begin_walk(f, (uint32_t)S[f]);
           }
         }
         if (uni64(__ballot(st != DONE)) == 0) break;

@@ -6,7 +6,8 @@ from oracle import oracle as O
 import lz_study as S
 from multiprocessing import Pool
 V = {"r3 kernel (K8: 4 hash bits + nib b4, 2/trip)": (0, 2), "K8 as is, 4/trip": (0, 4), "K16: hash4 + nib b4,b5,b6, 1/trip": (1, 1), "K16, 2/trip": (1, 2), "K16, 4/trip": (1, 4), "K16, 8/trip": (1, 8),
-     "K8': nib b4,b5, 2/trip": (2, 2), "K8', 4/trip": (2, 4)}
+     "K8': nib b4,b5, 2/trip": (2, 2), "K8', 4/trip": (2, 4), "K10: K8 + 2 bits of b5, 2/trip": (3, 2), "K10, 4/trip": (3, 4),
+     "K10h: 6 hash bits + nib b4, 2/trip": (4, 2), "K10b: 4 hash bits + 6 bits of b4, 2/trip": (5, 2), "K12: hash4 + nib b4,b5, 2/trip": (6, 2), "K12, 4/trip": (6, 4)}
 def work(buf):
     S.build(); L = C.CDLL(S.SO); L.study_trips.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     d = np.frombuffer(buf, np.uint8); cuts = O.cdc(d, O.default_cfg())

@@ -119,6 +119,21 @@ static int filt_rejects(const idx_t* x, uint32_t p, uint32_t q, uint32_t best, i
     for (uint32_t j = 0; j < 3; j++) if (best >= 4 + j && ((W[p + 4 + j] ^ W[q + 4 + j]) & 15)) return 1;
     return 0;
   }
+  if (fmode == 3) {   /* K8 + the two spare bits of a 14-bit S entry: low 2 bits of byte 5 */
+    if (hashdiff || (best >= 4 && ((W[p + 4] ^ W[q + 4]) & 15))) return 1;
+    return best >= 5 && ((W[p + 5] ^ W[q + 5]) & 3);
+  }
+  if (fmode == 4) {   /* 6 hash bits + low nibble of byte 4 (two spare bits of S spent on the hash) */
+    return ((hp >> 14) & 0x3F) != ((hq >> 14) & 0x3F) || (best >= 4 && ((W[p + 4] ^ W[q + 4]) & 15));
+  }
+  if (fmode == 5) {   /* 4 hash bits + low 6 bits of byte 4 */
+    return hashdiff || (best >= 4 && ((W[p + 4] ^ W[q + 4]) & 63));
+  }
+  if (fmode == 6) {   /* 12 bits: 4 hash bits + nibbles of bytes 4, 5 */
+    if (hashdiff) return 1;
+    for (uint32_t j = 0; j < 2; j++) if (best >= 4 + j && ((W[p + 4 + j] ^ W[q + 4 + j]) & 15)) return 1;
+    return 0;
+  }
   for (uint32_t j = 0; j < 2; j++) if (best >= 4 + j && ((W[p + 4 + j] ^ W[q + 4 + j]) & 15)) return 1;
   return 0;
 }
