@@ -27,12 +27,12 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 
 _CLS = {8: "1024,9216,9216,true,false,false,false", 9: "1024,21504,21504,true,true,true,true", 10: "1024,32768,32768,true,true,true,true",
         11: "512,65536,32768,false,false,false,false", 12: "1024,12288,12288,true,true,false,false", 13: "1024,16000,16000,true,true,true,false"}
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
-               14: "l1_encode_kernel<256,0,12288>", 15: "l1_encode_kernel<256,12288,32768>"}
+               14: "l1_encode_kernel<0,12288>", 15: "l1_encode_kernel<12288,32768>"}
 # match kernels: slots 8..13 = plain jobs of a size class, 18..23 = its dictionary jobs (last template argument)
 STAGE_NAMES.update({slot: f"l1_deflate_kernel<{args},false>" for slot, args in _CLS.items()})
 STAGE_NAMES.update({slot + 10: f"l1_deflate_kernel<{args},true>" for slot, args in _CLS.items()})
 # the encode kernels run twice per call: DELTA records (after the dictionary jobs; slots 30, 31), then FULL records (14, 15)
-STAGE_NAMES.update({30: "l1_encode_kernel<256,0,12288> [DELTA records]", 31: "l1_encode_kernel<256,12288,32768> [DELTA records]"})
+STAGE_NAMES.update({30: "l1_encode_kernel<0,12288> [DELTA records]", 31: "l1_encode_kernel<12288,32768> [DELTA records]"})
 # what the SQ counters say about the kernels that can be "dominant" (profiles/r1/h_pmc_sq_counters_2GB.csv)
 VALU_NOTE = {"l4_minhash_kernel": "; SQ counters: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x 8 waves per SIMD = 1.1, i.e. the vector ALUs are "
                                   "saturated (9.25 instructions per (distinct shingle, seed) pair)"}

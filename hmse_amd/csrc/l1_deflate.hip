@@ -290,8 +290,8 @@ __device__ __forceinline__ void put_bits(uint32_t* out, uint32_t off, uint32_t v
 //   zero run R:      R/138 x (18,138), then rem>=11 -> (18,rem) | rem>=3 -> (17,rem) | rem literal zeros
 //   non-zero run R:  the value, then (R-1)/6 x (16,6), then rem>=3 -> (16,rem) | rem literals
 // One wavefront; tokens are appended at sm->nr (lane 0 keeps the count).
-template <int NT>
-__device__ void rle_tree_wave(const uint8_t* l, uint32_t n, Small<NT>* sm, uint32_t tok_base, uint32_t* tok_end) {
+template <typename SM>
+__device__ void rle_tree_wave(const uint8_t* l, uint32_t n, SM* sm, uint32_t tok_base, uint32_t* tok_end) {
   const uint32_t lane = lane_id();
   uint64_t starts[5];
   uint32_t val[5];
@@ -1279,31 +1279,58 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
 }
 
 
-// ---- encode kernel: Huffman trees, block type, bit image -----------------------------------------------
-// One small workgroup per job; its LDS image is a few KiB plus the output image, so many jobs share a CU
-// and the serial parts of one (two-queue merge, stitching of the header) hide behind the others.
-template <int NT, int LMIN, int LCAP>
+// ---- encode kernel: Huffman trees, block type, bit image -----------------------------------------------------------------
+// One small workgroup per job record, many records per CU: the serial parts of one record (two-queue merge, stitching of the header)
+// hide behind the others.
+// Throughput = records in flight per CU / latency of one record, and a record's latency is mostly ONE lane's serial work (the two-queue
+// merges).  Measured, round 4, on round 3's kernel (256 threads, the whole bit image in LDS: 17.5 KiB, 8 records per CU = the wave limit):
+// padding its LDS so that 6 / 5 / 4 / 2 workgroups fit a CU takes it from 5.6 to 7.1 / 8.0 / 10.1 / 17.3 ms at 2 GB — time ~ 1 / records in
+// flight (profiles/r4/r4_encode_records_in_flight_2GB.txt).  So this kernel holds SIXTEEN records per CU: two wavefronts per record (the
+// wave limit again: 16 x 2 = 32) and 10 160 bytes of LDS (16 x 10 KiB = the CU's 160 KiB; 13 records for chunks above 12 KiB, whose batch
+// offsets need 2 KiB more) — the bit image is a 4 KiB WINDOW that slides over the stream: the token batches (64 tokens, alternating between
+// the two wavefronts) whose bits end inside the window are emitted, the finished 16-byte blocks are copied to the record's slot and the
+// window moves on (a typical 8 KiB chunk's ~2.7 KiB stream needs one window).  Same stream, bit for bit: 5.6 -> 4.2 ms at 2 GB.
+struct EncSmall {
+  uint32_t lf[288], df[32], cf[20];   // lf: later the bit offset of every token batch (u32[193])
+  uint8_t ll[288], dl[32], cl[20];
+  uint16_t lc[288], dc[32], cc[20];
+  uint8_t rle_sym[352], rle_eb[352], rle_ev[352];
+  uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
+  uint32_t job, spill;
+};
+template <int LMIN_, int LCAP_>
 struct EncLayout {
+  static constexpr int NT = 128, LMIN = LMIN_, LCAP = LCAP_;
+  static constexpr int NB_MAX = (LCAP + 63) / 64;       // token batches of a record (a token per byte at most)
+  static constexpr int NBLK = (NB_MAX + 1 + 63) / 64;   // 64-entry blocks of the batch-offset array
   static constexpr int SMALL_OFF = 0;
-  static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT>));
+  static constexpr int SMALL_SZ = align16((int)sizeof(EncSmall));
   static constexpr int HS_OFF = SMALL_OFF + SMALL_SZ;
   static constexpr int HS_SZ = align16((int)(sizeof(HuffL) + sizeof(HuffD)));
-  static constexpr int OUT_OFF = HS_OFF;                // the bit image reuses the Huffman scratch (dead once the codes exist)
-  static constexpr int OUT_SZ = align16(LCAP + 80);
-  static constexpr int TT_OFF = OUT_OFF + (OUT_SZ > HS_SZ ? OUT_SZ : HS_SZ);   // u32 TT[512]: a token's first part, ready to emit
-  static constexpr int TT_SZ = 512 * 4;
-  static constexpr int TOTAL = TT_OFF + TT_SZ;
+  static constexpr int TT_OFF = HS_OFF;                 // u32 TT[512] and the image window reuse the Huffman scratch (dead once the codes exist)
+  static constexpr int OUT_OFF = TT_OFF + 2048;
+  static constexpr int WIN_BYTES = 4096;                // the window; behind it: the last put's overhang (<= 8 bytes) and the 16-byte block in progress
+  static constexpr int OUT_SZ = HS_SZ - 2048;
+  static constexpr bool BOFF_IN_LF = NB_MAX + 1 <= 288; // batch offsets: in the dead histogram when they fit, else in an array of their own
+  static constexpr int BOFF_OFF = HS_OFF + HS_SZ;
+  static constexpr int BOFF_SZ = BOFF_IN_LF ? 0 : align16(4 * (NB_MAX + 1));
+  static constexpr int TOTAL = BOFF_OFF + BOFF_SZ;
+  static_assert(OUT_SZ >= WIN_BYTES + 64, "window + overhang");
+  static_assert(LCAP > 12288 || TOTAL <= 10240, "sixteen workgroups per CU for the records of chunks <= 12 KiB");
 };
 
-template <int NT, int LMIN, int LCAP>
-__global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
-  using EL = EncLayout<NT, LMIN, LCAP>;
+template <int LMIN, int LCAP>
+__global__ __launch_bounds__(128, 8) void l1_encode_kernel(Args a, const bool force_spill) {
+  using EL = EncLayout<LMIN, LCAP>;
+  constexpr uint32_t NT = EL::NT;
+  constexpr uint32_t WIN_BITS = EL::WIN_BYTES * 8;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Small<NT>& sm = *(Small<NT>*)(smem + EL::SMALL_OFF);
+  EncSmall& sm = *(EncSmall*)(smem + EL::SMALL_OFF);
   HuffL* const hsL = (HuffL*)(smem + EL::HS_OFF);
   HuffD* const hsD = (HuffD*)(smem + EL::HS_OFF + sizeof(HuffL));
-  uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
   uint32_t* const TT = (uint32_t*)(smem + EL::TT_OFF);
+  uint32_t* const out = (uint32_t*)(smem + EL::OUT_OFF);
+  uint32_t* const boff = EL::BOFF_IN_LF ? sm.lf : (uint32_t*)(smem + EL::BOFF_OFF);
   const uint32_t n_jobs = *a.n_jobs;
 #ifdef HMSE_DFL_STAMPS
   unsigned long long e_acc0 = 0, e_acc1 = 0, e_acc2 = 0, e_acc3 = 0, e_acc4 = 0, e_acc5 = 0, e_n = 0, e_last = clock64();
@@ -1312,16 +1339,16 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
 #define ESTAMP(v) do { } while (0)
 #endif
   for (;;) {
-  // The thread index is re-read behind a compiler barrier in every round: otherwise everything derived from it (dozens of
-  // `t < 288`-style masks, LDS addresses) is hoisted out of this persistent loop and held in registers across all phases —
-  // 38 VGPRs spilled to scratch under the 64-register cap that eight workgroups per CU need (tools/kernel_regs.py)
   uint32_t t = threadIdx.x;
+  // The thread index is re-read behind a compiler barrier in every round: otherwise everything derived from it (dozens of
+  // `t < 288`-style masks, LDS addresses) is hoisted out of this persistent loop and held in registers across all phases and
+  // spilled to scratch under the 64-register cap that eight wavefronts per SIMD need (tools/kernel_regs.py)
   asm volatile("" : "+v"(t));
-  const uint32_t lane = t & 63u, wave = t >> 6;
+  const uint32_t lane = t & 63u, wave = uni32(t >> 6);
   __syncthreads();
   if (t == 0) sm.job = atomicAdd(a.counter, 1u);
   __syncthreads();
-  const uint32_t ji = uni32(sm.job);   // (scalar metadata chain, as in the match kernel)
+  const uint32_t ji = uni32(sm.job);
   if (ji >= n_jobs) break;
   const uint32_t job = uni32(a.jobs[ji]);
   const uint64_t k = job >> 1;
@@ -1329,7 +1356,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   const uint64_t c = a.chunk_ids ? uni64(a.chunk_ids[k]) : k;
   const uint64_t cstart = uni64(a.cuts[c]);
   const uint32_t L = uni32((uint32_t)(a.cuts[c + 1] - cstart));
-  if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) continue;  // (lists are split by length: cannot happen)
+  if (L <= (uint32_t)LMIN || L > (uint32_t)LCAP) continue;      // (lists are split by length: cannot happen)
   uint32_t* len_out = variant ? a.len_delta : a.len_full;
   if (uni32(len_out[k]) == 0xFFFFFFFFu) continue;           // the match kernel could not take this job
   uint8_t* const rec = a.recs + uni64(a.rec_off[k]);
@@ -1344,10 +1371,10 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (t < 20) sm.cf[t] = 0;
   __syncthreads();
   ESTAMP(e_acc0);
-  // ---- phase 8: trees (wave 0: lit/len, wave 1: dist), fixed-code cost (wave 2) -----------------------
+  // ---- trees (wave 0: lit/len; wave 1: dist, then the fixed-code cost) ---------------------------------------------------
   if (wave == 0) huff_lengths_wave(sm.lf, 286, 15, sm.ll, hsL);
-  if (wave == 1) huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
-  if (wave == 2) {
+  else {
+    huff_lengths_wave(sm.df, 30, 15, sm.dl, hsD);
     uint32_t fb = 0, xb = 0;
     for (uint32_t s = lane; s < 286; s += 64) { fb += sm.lf[s] * fixed_len(s); if (s >= 257) xb += sm.lf[s] * len_extra_bits(s); }
     if (lane < 30) { fb += sm.df[lane] * 5u; xb += sm.df[lane] * dist_extra_bits(lane); }
@@ -1356,10 +1383,10 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   }
   __syncthreads();
   ESTAMP(e_acc1);
-  // ---- phase 9: code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) ---------------------------
+  // ---- code-length RLE + CL tree (wave 0), dynamic data bits (wave 1) -----------------------------------------------------
   if (wave == 0) {
     uint32_t nlit = 286, ndist = 30;
-    {  // trailing zero lengths: highest used symbol via ballots
+    {
       uint32_t hi = 0;
       for (uint32_t b = 0; b < 320; b += 64) { const uint32_t s = b + lane; const uint64_t m = __ballot(s < 286 && sm.ll[s] != 0); if (m) hi = b + 64 - (uint32_t)__builtin_clzll(m); }
       nlit = hi < 257 ? 257 : hi;
@@ -1367,8 +1394,8 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
       ndist = md ? 64 - (uint32_t)__builtin_clzll(md) : 1u;
     }
     uint32_t e1, e2;
-    rle_tree_wave<NT>(sm.ll, nlit, &sm, 0, &e1);
-    rle_tree_wave<NT>(sm.dl, ndist, &sm, e1, &e2);
+    rle_tree_wave(sm.ll, nlit, &sm, 0, &e1);
+    rle_tree_wave(sm.dl, ndist, &sm, e1, &e2);
     for (uint32_t i = lane; i < e2; i += 64) atomicAdd(&sm.cf[sm.rle_sym[i]], 1u);
     if (lane == 0) { sm.nlit = nlit; sm.ndist = ndist; sm.nr = e2; }
     wave_sync();
@@ -1381,8 +1408,7 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     for (uint32_t i = lane; i < e2; i += 64) cb += sm.cl[sm.rle_sym[i]] + sm.rle_eb[i];
     cb = wave_sum(cb);
     if (lane == 0) { sm.ncl = ncl; sm.cl_bits = cb; }
-  }
-  if (wave == 1) {
+  } else {
     uint32_t db = 0;
     for (uint32_t s = lane; s < 286; s += 64) db += sm.lf[s] * sm.ll[s];
     if (lane < 30) db += sm.df[lane] * sm.dl[lane];
@@ -1402,27 +1428,29 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
     sm.hdr_bits = mode == 2 ? dhdr : 3u;
   }
   __syncthreads();
-  const uint32_t mode = sm.mode;
+  const uint32_t mode = uni32(sm.mode);
   if (mode == 0) {
     if (t == 0) {
       slot[0] = 1; slot[1] = (uint8_t)L; slot[2] = (uint8_t)(L >> 8); slot[3] = (uint8_t)~L; slot[4] = (uint8_t)(~L >> 8);
       len_out[k] = 5 + L;
     }
     for (uint32_t x = t; x < L; x += NT) slot[5 + x] = lit[x];
-    continue;  // next job (this workgroup is persistent)
+    continue;
   }
   ESTAMP(e_acc2);
-  // ---- phase 10: code tables ------------------------------------------------------------------------------
+  // ---- code tables ------------------------------------------------------------------------------------------------------------
   if (mode == 1) {
     for (uint32_t s = t; s < 288; s += NT) sm.ll[s] = (uint8_t)fixed_len(s);
     if (t < 32) sm.dl[t] = 5;
     __syncthreads();
   }
   if (wave == 0) huff_codes_wave(sm.ll, mode == 1 ? 288 : 286, sm.lc, hsL->cnt);
-  if (wave == 1) huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
-  if (wave == 2 && mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsL->key);
+  else {
+    huff_codes_wave(sm.dl, mode == 1 ? 32 : 30, sm.dc, hsD->cnt);
+    if (mode == 2) huff_codes_wave(sm.cl, 19, sm.cc, hsD->cnt);
+  }
   __syncthreads();
-  for (uint32_t i = t; i < (L + 64) / 4; i += NT) out[i] = 0;  // (the image shares LDS with the scratch used above)
+  for (uint32_t i = t; i < (uint32_t)EL::OUT_SZ / 4; i += NT) out[i] = 0;
   // TT[low half of a token] = the bits of its first part (literal code | length code + extra bits: <= 20 bits) | bit count << 24;
   // df[distance code] = code | length << 16 (the histogram is dead).  The emit loops then do one table read per part.
   for (uint32_t ts = t; ts < 512u; ts += NT) {
@@ -1439,14 +1467,65 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
   if (t < 32) sm.df[t] = (uint32_t)sm.dc[t] | ((uint32_t)sm.dl[t] << 16);
   __syncthreads();
   ESTAMP(e_acc3);
-  // ---- phase 11: emit ----------------------------------------------------------------------------------------
+  // ---- emit ---------------------------------------------------------------------------------------------------------------------
+  auto tokbits = [&](uint32_t tk) -> uint32_t {
+    const uint32_t ts = tk & 0xFFFFu;
+    uint32_t b = TT[ts] >> 24;
+    if (ts >= 256u) {
+      uint32_t dcode, deb, dev;
+      dist_sym(tk >> 16, dcode, deb, dev);
+      b += (sm.df[dcode] >> 16) + deb;
+    }
+    return b;
+  };
+  const uint32_t nb = (ntok + 63u) >> 6;   // token batches; batch b belongs to wavefront b & 1
+  // (a) bits per batch (the histogram is dead: boff = lf), four batches' loads in flight per wavefront
+  for (uint32_t b = wave; b < nb; b += 8u) {
+    uint32_t tk[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) { const uint32_t i = ((b + 2u * u) << 6) + lane; tk[u] = i < ntok ? tok[i] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) {
+      const uint32_t bits = wave_sum(tk[u] != 0xFFFFFFFFu ? tokbits(tk[u]) : 0u);
+      if (lane == 0 && b + 2u * u < nb) boff[b + 2u * u] = bits;
+    }
+  }
+  __syncthreads();
+  // (b) exclusive scan -> the bit offset of every batch in the stream (boff[nb] = where the end-of-block code goes)
+  if (wave == 0) {
+    uint32_t carry = sm.hdr_bits;
+#pragma unroll
+    for (uint32_t kx = 0; kx < (uint32_t)EL::NBLK; kx++) {
+      const uint32_t idx = kx * 64u + lane;
+      const uint32_t v = idx < nb ? boff[idx] : 0u;
+      const uint32_t inc = wave_incl_scan(v);
+      if (idx < nb) boff[idx] = carry + inc - v;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) boff[nb] = carry;
+    // A FULL record's stream is written OVER its token list (one record per chunk), window by window — while later tokens
+    // are still to be read: safe as long as the stream bytes below a window edge do not outnumber the bytes of the tokens consumed so
+    // far (4 per token), i.e. <= 32 bits per token on average from the start of the record.  That holds for every record we have seen
+    // (the fixed code's dearest token is 31 bits; 64 literals buy 23 x 64 bits of slack) but is no theorem for a dynamic code, so it is
+    // CHECKED here at every batch boundary a window could end at, and a record that fails it sends its finished windows to this
+    // workgroup's 32 KiB of the match kernels' global scratch (idle now) and moves them into the slot when its last token is read.
+    bool risky = false;
+#pragma unroll
+    for (uint32_t kx = 0; kx < (uint32_t)EL::NBLK; kx++) {
+      const uint32_t idx = kx * 64u + lane;
+      if (idx >= 1u && idx < nb) { const uint32_t bo = boff[idx]; risky = risky || (bo >= WIN_BITS - 3200u && (bo >> 3) > 256u * idx); }
+    }
+    const bool any = __ballot(risky) != 0ull;
+    if (lane == 0) sm.spill = (variant == 0u && (any || force_spill)) ? 1u : 0u;
+  }
+  __syncthreads();
+  // (c) header (wave 0; it lies inside the first window: <= 17 + 57 + 316 x 14 bits)
   if (wave == 0) {
     if (lane == 0) { put_bits(out, 0, 1, 1); put_bits(out, 1, mode, 2); }
     if (mode == 2) {
       const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
       if (lane == 0) { put_bits(out, 3, sm.nlit - 257, 5); put_bits(out, 8, sm.ndist - 1, 5); put_bits(out, 13, sm.ncl - 4, 4); }
       if (lane < sm.ncl) put_bits(out, 17 + 3 * lane, sm.cl[order[lane]], 3);
-      // code-length tokens: contiguous token blocks per lane, wave prefix scan of their bit counts
       const uint32_t nr = sm.nr, per = (nr + 63) / 64;
       const uint32_t i0 = lane * per, i1 = (i0 + per) < nr ? (i0 + per) : nr;
       uint32_t bits = 0;
@@ -1460,81 +1539,76 @@ __global__ __launch_bounds__(NT, 8) void l1_encode_kernel(Args a) {
       }
     }
   }
-  // token bits: every wavefront owns a contiguous token range and walks it 64 tokens at a time (coalesced
-  // dword loads); bit offsets come from a wave prefix scan per step plus the wave's start offset
-  constexpr uint32_t NWV = NT / 64;
-  const uint32_t wq = ((ntok + NWV - 1) / NWV + 63u) & ~63u;  // tokens per wave, multiple of 64
-  const uint32_t tw0 = wave * wq, tw1 = (tw0 + wq) < ntok ? (tw0 + wq) : ntok;
-  auto tokbits = [&](uint32_t tk) -> uint32_t {
-    const uint32_t ts = tk & 0xFFFFu;
-    uint32_t b = TT[ts] >> 24;
-    if (ts >= 256u) {
-      uint32_t dcode, deb, dev;
-      dist_sym(tk >> 16, dcode, deb, dev);
-      b += (sm.df[dcode] >> 16) + deb;
-    }
-    return b;
-  };
-  uint32_t mybits = 0;
-  {  // four independent token loads in flight per lane (the records left the caches long ago: one HBM round trip per load)
-    uint32_t i = tw0 + lane;
-    for (; i + 192u < tw1; i += 256u) {
-      const uint32_t t0 = tok[i], t1 = tok[i + 64u], t2 = tok[i + 128u], t3 = tok[i + 192u];
-      mybits += tokbits(t0) + tokbits(t1) + tokbits(t2) + tokbits(t3);
-    }
-    for (; i < tw1; i += 64u) mybits += tokbits(tok[i]);
-  }
-  mybits = wave_sum(mybits);
-  if (lane == 0) sm.red[wave] = mybits;
-  __syncthreads();
-  uint32_t total = 0, wstart = sm.hdr_bits;
+  // (d) the window slides over the batches: [seg, e) = the batches that END inside the window that starts at base_bits
+  const uint32_t end_bits = uni32(boff[nb]);
+  const uint32_t eob_len = sm.ll[256];
+  const bool spill = uni32(sm.spill) != 0u;
+  uint8_t* const wdst = spill ? a.scratch2 + (size_t)blockIdx.x * 32768u : slot;   // where finished windows go (the last one always goes to the slot)
+  uint32_t seg = 0, base_bits = 0;
+  for (;;) {
+    uint32_t cnt = 0;
 #pragma unroll
-  for (uint32_t w = 0; w < NWV; w++) { const uint32_t c = sm.red[w]; total += c; if (w < wave) wstart += c; }
-  {
-    uint32_t running = wstart;
-    uint32_t tk_n1 = (tw0 + lane) < tw1 ? tok[tw0 + lane] : 0u, tk_n2 = (tw0 + lane + 64u) < tw1 ? tok[tw0 + lane + 64u] : 0u;
-    for (uint32_t i0 = tw0; i0 < tw1; i0 += 64) {
-      const uint32_t i = i0 + lane;
-      const uint32_t tk = tk_n1;      // loaded two steps ahead
-      tk_n1 = tk_n2;
-      tk_n2 = (i + 128u) < tw1 ? tok[i + 128u] : 0u;
-      // the token's bits: literal / length part (v1, nb1 <= 20 bits) from the table, distance part (v2, nb2 <= 28 bits)
-      uint32_t v1 = 0, nb1 = 0, v2 = 0, nb2 = 0;
-      if (i < tw1) {
-        const uint32_t ts = tk & 0xFFFFu;
-        const uint32_t e = TT[ts];
-        v1 = e & 0xFFFFFFu; nb1 = e >> 24;
-        if (ts >= 256u) {
-          uint32_t dcode, deb, dev;
-          dist_sym(tk >> 16, dcode, deb, dev);
-          const uint32_t d = sm.df[dcode], l2 = d >> 16;
-          v2 = (d & 0xFFFFu) | (dev << l2); nb2 = l2 + deb;
+    for (uint32_t kx = 0; kx < (uint32_t)EL::NBLK; kx++) {
+      const uint32_t idx = seg + 1u + kx * 64u + lane;
+      cnt += (uint32_t)__builtin_popcountll(__ballot(idx <= nb && boff[idx <= (uint32_t)EL::NB_MAX ? idx : 0u] - base_bits <= WIN_BITS));
+    }
+    const uint32_t e = uni32(seg + cnt);   // (> seg unless seg == nb: a batch is <= 64 x 48 bits, the window starts < 128 bits before it)
+    {
+      uint32_t b = seg + ((seg ^ wave) & 1u);
+      uint32_t tk_n = (b < e && ((b << 6) + lane) < ntok) ? tok[(b << 6) + lane] : 0xFFFFFFFFu;
+      for (; b < e; b += 2u) {
+        const uint32_t tk = tk_n;
+        { const uint32_t b2 = b + 2u; tk_n = (b2 < e && ((b2 << 6) + lane) < ntok) ? tok[(b2 << 6) + lane] : 0xFFFFFFFFu; }
+        uint32_t v1 = 0, nb1 = 0, v2 = 0, nb2 = 0;
+        if (tk != 0xFFFFFFFFu) {
+          const uint32_t ts = tk & 0xFFFFu;
+          const uint32_t en = TT[ts];
+          v1 = en & 0xFFFFFFu; nb1 = en >> 24;
+          if (ts >= 256u) {
+            uint32_t dcode, deb, dev;
+            dist_sym(tk >> 16, dcode, deb, dev);
+            const uint32_t d = sm.df[dcode], l2 = d >> 16;
+            v2 = (d & 0xFFFFu) | (dev << l2); nb2 = l2 + deb;
+          }
         }
-      }
-      const uint32_t b = nb1 + nb2;
-      const uint32_t inc = wave_incl_scan(b);
-      const uint32_t off = running + inc - b;
-      running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-      if (b) {   // one put of up to 48 bits: at most three dwords of the image
-        const uint64_t v = (uint64_t)v1 | ((uint64_t)v2 << nb1);
-        const uint32_t w = off >> 5, sh = off & 31u;
-        atomicOr(&out[w], (uint32_t)v << sh);
-        if (sh + b > 32u) {
-          const uint64_t rest = (v >> 1) >> (31u - sh);
-          atomicOr(&out[w + 1], (uint32_t)rest);
-          if (sh + b > 64u) atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
+        const uint32_t bb = nb1 + nb2;
+        const uint32_t inc = wave_incl_scan(bb);
+        const uint32_t off = uni32(boff[b]) - base_bits + inc - bb;
+        if (bb) {   // one put of up to 48 bits: at most three dwords of the image
+          const uint64_t v = (uint64_t)v1 | ((uint64_t)v2 << nb1);
+          const uint32_t w = off >> 5, sh = off & 31u;
+          atomicOr(&out[w], (uint32_t)v << sh);
+          if (sh + bb > 32u) {
+            const uint64_t rest = (v >> 1) >> (31u - sh);
+            atomicOr(&out[w + 1], (uint32_t)rest);
+            if (sh + bb > 64u) atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
+          }
         }
       }
     }
+    if (e >= nb) break;
+    __syncthreads();
+    // move the window: whole 16-byte blocks below the next batch's first bit go to the slot, the block in progress moves to the front
+    const uint32_t nbase = uni32(boff[e]) & ~127u;
+    const uint32_t nflush = (nbase - base_bits) >> 3;
+    for (uint32_t i = t * 16; i < nflush; i += NT * 16) { const uint4 v = *(const uint4*)((const uint8_t*)out + i); *(uint4*)(wdst + (base_bits >> 3) + i) = v; }
+    const uint4 tail = *(const uint4*)((const uint8_t*)out + nflush);
+    __syncthreads();
+    for (uint32_t i = t; i < (uint32_t)EL::OUT_SZ / 4; i += NT) out[i] = 0;
+    __syncthreads();
+    if (t == 0) *(uint4*)out = tail;
+    __syncthreads();
+    base_bits = nbase; seg = e;
   }
-  const uint32_t end_bits = sm.hdr_bits + total;
-  if (t == 0) put_bits(out, end_bits, sm.lc[256], sm.ll[256]);
+  __syncthreads();
+  if (t == 0) put_bits(out, end_bits - base_bits, sm.lc[256], eob_len);
   __syncthreads();
   ESTAMP(e_acc4);
-  const uint32_t nbytes = (end_bits + sm.ll[256] + 7) >> 3;
-  for (uint32_t i = t * 16; i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned; whole 16-byte stores stay inside it (rec_slot_off)
+  const uint32_t nbytes = (end_bits + eob_len + 7) >> 3;
+  if (spill) for (uint32_t i = t * 16; i < (base_bits >> 3); i += NT * 16) *(uint4*)(slot + i) = *(const uint4*)(wdst + i);   // (every token has been read)
+  for (uint32_t i = t * 16; (base_bits >> 3) + i < nbytes; i += NT * 16) {  // the slot is 16-byte aligned; whole 16-byte stores stay inside it (rec_slot_off)
     const uint4 v = *(const uint4*)((const uint8_t*)out + i);
-    *(uint4*)(slot + i) = v;
+    *(uint4*)(slot + (base_bits >> 3) + i) = v;
   }
   if (t == 0) len_out[k] = nbytes;
   ESTAMP(e_acc5);
@@ -1790,7 +1864,7 @@ static Ws carve(void* ws, uint64_t n_sel) {
   r.list_stride = 2 * n_sel;
   r.lists = w.take<uint32_t>(N_LIST * r.list_stride);
   r.scratch = w.take<uint8_t>((size_t)N_WG_B * hmse_align_up(sizeof(Scratch), 256));
-  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(8 * 32768, 256));   // per workgroup: match distances / lengths (3 x 32768) + the plain jobs' hand-out lists (2 x u16[32768] at byte 98304)
+  r.scratch2 = w.take<uint8_t>((size_t)512 * hmse_align_up(8 * 32768, 256));   // per match workgroup: match distances / lengths (3 x 32768) + the hand-out list (u32[32768] at byte 98304); per encode workgroup (4096 x 32 KiB, after the match kernels): finished windows of a record that may not be written in place yet
   r.fixed_bytes = w.off;
   r.recs = r.scratch ? (uint8_t*)ws + w.off : nullptr;
   return r;
@@ -1902,18 +1976,8 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
   a.prof_ctr = g_hmse_prof ? g_hmse_prof_ctr : nullptr; a.prof_slot = 0;
   // Order (rule 7): dictionary jobs -> their DELTA encodes -> redo_kernel (chunks whose delta is no quick accept join the plain
   // lists) -> plain jobs -> FULL encodes.  Profile slots: plain 8..13, dictionary 18..23, encode FULL 14 / 15, encode DELTA 30 / 31.
-  using E1 = EncLayout<256, 0, 12288>;
-  using E2 = EncLayout<256, 12288, 32768>;
-  {
-    static std::once_flag enc_once;
-    static hipError_t enc_rc = hipSuccess;
-    std::call_once(enc_once, [] {
-      enc_rc = hipFuncSetAttribute((const void*)l1_encode_kernel<256, 0, 12288>, hipFuncAttributeMaxDynamicSharedMemorySize, E1::TOTAL);
-      if (enc_rc == hipSuccess)
-        enc_rc = hipFuncSetAttribute((const void*)l1_encode_kernel<256, 12288, 32768>, hipFuncAttributeMaxDynamicSharedMemorySize, E2::TOTAL);
-    });
-    if (enc_rc != hipSuccess) return HMSE_EHIP;
-  }
+  // HMSE_ENC_FORCE_SPILL=1 (tests): every FULL record takes the encode kernel's spill path (finished windows via the global scratch)
+  static const bool enc_force_spill = getenv("HMSE_ENC_FORCE_SPILL") != nullptr;
 #define HMSE_DFL_LAUNCH(DICT_, LIST, SLOT, GRID, ...)                                                               \
   sel(LIST); a.prof_slot = (SLOT);                                                                                   \
   PROF_BEGIN(SLOT, stream);                                                                                          \
@@ -1922,11 +1986,11 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
 #define HMSE_DFL_ENCODE(LIST1, SLOT1, LIST2, SLOT2)                                                                  \
   sel(LIST1); a.prof_slot = (SLOT1);                                                                                 \
   PROF_BEGIN(SLOT1, stream);                                                                                         \
-  l1_encode_kernel<256, 0, 12288><<<dim3((uint32_t)(max_jobs < 2048 ? max_jobs : 2048)), dim3(256), E1::TOTAL, stream>>>(a);        \
+  l1_encode_kernel<0, 12288><<<dim3((uint32_t)(max_jobs < 4096 ? max_jobs : 4096)), dim3(128), EncLayout<0, 12288>::TOTAL, stream>>>(a, enc_force_spill);           \
   PROF_END(SLOT1, stream); dbg(SLOT1);                                                                               \
   sel(LIST2); a.prof_slot = (SLOT2);                                                                                 \
   PROF_BEGIN(SLOT2, stream);                                                                                         \
-  l1_encode_kernel<256, 12288, 32768><<<dim3((uint32_t)(max_jobs < 1024 ? max_jobs : 1024)), dim3(256), E2::TOTAL, stream>>>(a);    \
+  l1_encode_kernel<12288, 32768><<<dim3((uint32_t)(max_jobs < 3328 ? max_jobs : 3328)), dim3(128), EncLayout<12288, 32768>::TOTAL, stream>>>(a, enc_force_spill);   \
   PROF_END(SLOT2, stream); dbg(SLOT2);                                                                               \
   HMSE_LAUNCH_CHECK();
   if (base) {

@@ -364,6 +364,53 @@ def test_l1_deflate_near_incompressible_record_slots(orc, dev):
         assert np.array_equal(out.cpu().numpy(), want_out)
 
 
+def test_l1_encode_window_slides_over_long_streams(orc, dev):
+    """The encode kernel assembles a record's bit image in a 4 KiB LDS window that slides over the stream (round 4): records whose
+    stream is several windows long in both record classes (chunks <= 12 KiB and above) — 5..7 bits of entropy per byte, so the
+    dynamic block beats the stored one and the stream is 0.6..0.9 of the chunk —, streams that end within a few bytes of a window
+    edge, and text in between.  Streams equal the oracle's and inflate through stock zlib."""
+    import zlib
+    from hmse_amd import IngestConfig, ops
+    cfg = IngestConfig()
+    oc = ocfg(orc, cfg)
+    rng = np.random.Generator(np.random.PCG64(77))
+    text = words_text(40000, seed=5)
+    parts = []
+    for L, hi in ((12288, 64), (12288, 128), (12000, 32), (9000, 200), (8192, 16), (32768, 128), (30000, 64), (20000, 32), (16384, 250)):
+        parts.append(rng.integers(0, hi, L, dtype=np.uint8))
+        parts.append(text[: 3000 + 7 * len(parts)])
+    # stream lengths around the window edge: 5-bit symbols -> ~0.63 bytes of stream per byte; lengths stepped so that the ends of the
+    # streams sweep across 4096 and 8192 bytes
+    for L in list(range(6450, 6650, 8)) + list(range(12950, 13150, 8)):
+        parts.append(rng.integers(0, 32, L, dtype=np.uint8))
+    data = np.concatenate(parts)
+    cuts = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    want_out, want_off, want_kind = orc.deflate_chunks(data, cuts, oc, None, None)
+    sizes = np.diff(want_off.astype(np.int64))
+    assert (sizes > 4096).sum() >= 10 and (sizes > 8192).sum() >= 5 and (np.abs(sizes - 4096) < 24).any() and (np.abs(sizes - 8192) < 24).any()
+    out, off, kind = ops.l1_deflate(to_dev(data, dev), to_dev(cuts.astype(np.int64), dev), cfg, None, None)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert np.array_equal(kind.cpu().numpy(), want_kind)
+    o = out.cpu().numpy()
+    assert np.array_equal(o, want_out)
+    for j in range(len(parts)):
+        assert zlib.decompressobj(-15).decompress(o[int(want_off[j]):int(want_off[j + 1])].tobytes()) == parts[j].tobytes()
+
+
+def test_l1_encode_spill_path_gives_the_same_streams(dev):
+    """A FULL record's stream is written over its token list window by window; a record for which that could overrun tokens still to
+    be read (more than 32 bits per token on average: never seen) parks its finished windows in the global scratch.  The path is forced
+    for every record in a child process (HMSE_ENC_FORCE_SPILL is read once per process): same streams as the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HMSE_ENC_FORCE_SPILL="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "enc_spill_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "spill path OK" in r.stdout
+
+
 def test_l1_deflate_selection(orc, dev, corpus_small):
     from hmse_amd import IngestConfig, ops
     cfg = IngestConfig()
