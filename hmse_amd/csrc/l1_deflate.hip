@@ -1545,6 +1545,11 @@ __global__ __launch_bounds__(128, 8) void l1_encode_kernel(Args a, const bool fo
   const bool spill = uni32(sm.spill) != 0u;
   uint8_t* const wdst = spill ? a.scratch2 + (size_t)blockIdx.x * 32768u : slot;   // where finished windows go (the last one always goes to the slot)
   uint32_t seg = 0, base_bits = 0;
+  // this wavefront's batches are b = wave, wave + 2, ...; their tokens are loaded three batches ahead (the loads outlive the window moves: a
+  // move overwrites consumed tokens only)
+  auto ldtok = [&](uint32_t b) -> uint32_t { const uint32_t i = (b << 6) + lane; return i < ntok ? tok[i] : 0xFFFFFFFFu; };
+  uint32_t nxt = wave;
+  uint32_t pf0 = ldtok(nxt), pf1 = ldtok(nxt + 2u), pf2 = ldtok(nxt + 4u);
   for (;;) {
     uint32_t cnt = 0;
 #pragma unroll
@@ -1553,36 +1558,33 @@ __global__ __launch_bounds__(128, 8) void l1_encode_kernel(Args a, const bool fo
       cnt += (uint32_t)__builtin_popcountll(__ballot(idx <= nb && boff[idx <= (uint32_t)EL::NB_MAX ? idx : 0u] - base_bits <= WIN_BITS));
     }
     const uint32_t e = uni32(seg + cnt);   // (> seg unless seg == nb: a batch is <= 64 x 48 bits, the window starts < 128 bits before it)
-    {
-      uint32_t b = seg + ((seg ^ wave) & 1u);
-      uint32_t tk_n = (b < e && ((b << 6) + lane) < ntok) ? tok[(b << 6) + lane] : 0xFFFFFFFFu;
-      for (; b < e; b += 2u) {
-        const uint32_t tk = tk_n;
-        { const uint32_t b2 = b + 2u; tk_n = (b2 < e && ((b2 << 6) + lane) < ntok) ? tok[(b2 << 6) + lane] : 0xFFFFFFFFu; }
-        uint32_t v1 = 0, nb1 = 0, v2 = 0, nb2 = 0;
-        if (tk != 0xFFFFFFFFu) {
-          const uint32_t ts = tk & 0xFFFFu;
-          const uint32_t en = TT[ts];
-          v1 = en & 0xFFFFFFu; nb1 = en >> 24;
-          if (ts >= 256u) {
-            uint32_t dcode, deb, dev;
-            dist_sym(tk >> 16, dcode, deb, dev);
-            const uint32_t d = sm.df[dcode], l2 = d >> 16;
-            v2 = (d & 0xFFFFu) | (dev << l2); nb2 = l2 + deb;
-          }
+    for (; nxt < e; nxt += 2u) {
+      const uint32_t b = nxt;
+      const uint32_t tk = pf0;
+      pf0 = pf1; pf1 = pf2; pf2 = ldtok(b + 6u);
+      uint32_t v1 = 0, nb1 = 0, v2 = 0, nb2 = 0;
+      if (tk != 0xFFFFFFFFu) {
+        const uint32_t ts = tk & 0xFFFFu;
+        const uint32_t en = TT[ts];
+        v1 = en & 0xFFFFFFu; nb1 = en >> 24;
+        if (ts >= 256u) {
+          uint32_t dcode, deb, dev;
+          dist_sym(tk >> 16, dcode, deb, dev);
+          const uint32_t d = sm.df[dcode], l2 = d >> 16;
+          v2 = (d & 0xFFFFu) | (dev << l2); nb2 = l2 + deb;
         }
-        const uint32_t bb = nb1 + nb2;
-        const uint32_t inc = wave_incl_scan(bb);
-        const uint32_t off = uni32(boff[b]) - base_bits + inc - bb;
-        if (bb) {   // one put of up to 48 bits: at most three dwords of the image
-          const uint64_t v = (uint64_t)v1 | ((uint64_t)v2 << nb1);
-          const uint32_t w = off >> 5, sh = off & 31u;
-          atomicOr(&out[w], (uint32_t)v << sh);
-          if (sh + bb > 32u) {
-            const uint64_t rest = (v >> 1) >> (31u - sh);
-            atomicOr(&out[w + 1], (uint32_t)rest);
-            if (sh + bb > 64u) atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
-          }
+      }
+      const uint32_t bb = nb1 + nb2;
+      const uint32_t inc = wave_incl_scan(bb);
+      const uint32_t off = uni32(boff[b]) - base_bits + inc - bb;
+      if (bb) {   // one put of up to 48 bits: at most three dwords of the image
+        const uint64_t v = (uint64_t)v1 | ((uint64_t)v2 << nb1);
+        const uint32_t w = off >> 5, sh = off & 31u;
+        atomicOr(&out[w], (uint32_t)v << sh);
+        if (sh + bb > 32u) {
+          const uint64_t rest = (v >> 1) >> (31u - sh);
+          atomicOr(&out[w + 1], (uint32_t)rest);
+          if (sh + bb > 64u) atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
         }
       }
     }
