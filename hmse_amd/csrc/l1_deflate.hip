@@ -49,6 +49,13 @@ __device__ __forceinline__ void ld64a(const uint8_t* W, uint32_t off, uint32_t& 
   const uint32_t a = w[0], b = w[1], c = w[2];
   x0 = alignb(b, a, off); x1 = alignb(c, b, off);
 }
+// The sort's key of position `off`: the hash product of its four bytes in bits 16..31 (bucket = bits 20..31, filter bits = 16..19) and the
+// low nibble of its byte 4 in bits 0..3 — all from the two aligned dwords the hash needs anyway (byte 4 lies in the second one).
+__device__ __forceinline__ uint32_t sort_key(const uint8_t* W, uint32_t off) {
+  const uint32_t* w = (const uint32_t*)(W + (off & ~3u));
+  const uint32_t a = w[0], b = w[1];
+  return ((alignb(b, a, off) * 0x9E3779B1u) & 0xFFFF0000u) | ((b >> ((off & 3u) * 8u)) & 0x0Fu);
+}
 // N * 8 bytes at W + off as 64-bit pieces
 template <int N>
 __device__ __forceinline__ void ldNa(const uint8_t* W, uint32_t off, uint64_t (&x)[N]) {
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
       // (filter byte of a position: low nibble of its byte 4 | four more bits of its hash product, see the matcher's `rejects`)
       uint32_t q = t, h = 0, before = 0, hx = 0;
       bool act = q < nh;
-      if (act) { hx = ld32a(W, q) * 0x9E3779B1u; h = hx >> (32 - HB); before = cur_get(cur, h); }
+      if (act) { hx = sort_key(W, q); h = hx >> (32 - HB); before = cur_get(cur, h); }
       __syncthreads();
       for (uint32_t q0 = 0; q0 < nh; q0 += NT) {
         if (act) S[cur_inc(cur, h)] = (uint16_t)q;
@@ -603,9 +610,9 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
         const uint32_t qn = q0 + NT + t;
         const bool actn = qn < nh;
         uint32_t hn = 0, beforen = 0, hxn = 0;
-        if (actn) { hxn = ld32a(W, qn) * 0x9E3779B1u; hn = hxn >> (32 - HB); beforen = cur_get(cur, hn); }
+        if (actn) { hxn = sort_key(W, qn); hn = hxn >> (32 - HB); beforen = cur_get(cur, hn); }
         __syncthreads();
-        if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = (uint8_t)((W[q + 4] & 0x0Fu) | ((hx >> 12) & 0xF0u)); }
+        if (act) { S[before + r] = (uint16_t)q; if constexpr (!NOK) K[before + r] = (uint8_t)((hx & 0x0Fu) | ((hx >> 12) & 0xF0u)); }
         q = qn; act = actn; h = hn; before = beforen; hx = hxn;
       }
       __syncthreads();  // cursor h now = end of bucket h
