@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-_CLS = {8: "1024,9216,9216,true,false,false,false", 9: "1024,21504,21504,true,true,true,true", 10: "1024,32768,32768,true,true,true,true",
-        11: "512,65536,32768,false,false,false,false", 12: "1024,12288,12288,true,true,false,false", 13: "1024,16000,16000,true,true,true,false"}
+_CLS = {8: "1024,10048,10048,true,false,false,false", 9: "1024,22976,22976,true,true,true,true", 10: "1024,32768,32768,true,true,true,true",
+        11: "1024,65536,32768,false,false,false,false", 12: "1024,13952,13952,true,true,false,false", 13: "1024,17408,17408,true,true,true,false"}
 STAGE_NAMES = {2: "l2_hash_kernel", 3: "l3_sha256_kernel", 5: "l4_minhash_kernel",
                14: "l1_encode_kernel<0,12288>", 15: "l1_encode_kernel<12288,32768>"}
 # match kernels: slots 8..13 = plain jobs of a size class, 18..23 = its dictionary jobs (last template argument)
@@ -410,7 +410,8 @@ def main():
         # FULL and the DELTA token list); encode jobs: one per record
 
         def by_class(T, Ltok, off):
-            cls = torch.where(T <= 9216, 0, torch.where(T <= 12288, 4, torch.where(T <= 16000, 5, torch.where(T <= 21504, 1, torch.where(T <= 32768, 2, 3)))))
+            c_s, c_s2, c_sg, c_sg2, c_sg3 = ops.DEFLATE_CLASS_CAPS
+            cls = torch.where(T <= c_s, 0, torch.where(T <= c_s2, 4, torch.where(T <= c_sg, 5, torch.where(T <= c_sg2, 1, torch.where(T <= c_sg3, 2, 3)))))
             for c, slot in DEFLATE_CLASS_SLOT.items():
                 m = cls == c
                 # match kernel: window read + token list written (4 B per token, COUNTED by the kernel: hmse_profile_counter)

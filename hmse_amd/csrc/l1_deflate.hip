@@ -120,23 +120,35 @@ struct HuffScratchT {
 using HuffL = HuffScratchT<288>;
 using HuffD = HuffScratchT<32>;
 
-// small per-workgroup state (always in LDS)
-template <int NT>
+// small per-workgroup state of the match kernel (always in LDS; the encode kernel has its own: EncSmall)
+template <int NT, bool WQ>
 struct Small {
-  uint32_t lf[288], df[32], cf[20];
-  uint8_t ll[288], dl[32], cl[20];
-  uint16_t lc[288], dc[32], cc[20];
-  uint8_t rle_sym[352], rle_eb[352], rle_ev[352];
+  uint32_t lf[288], df[32];   // literal / length and distance histograms of the job's tokens
   uint32_t red[NT / 64 + 1];
-  uint32_t nr, nlit, ndist, ncl, mode, hdr_bits, fixed_bits, extra_bits, data_bits, cl_bits;
-  uint32_t job, qhead;
-  uint32_t ocnt[4];   // plain jobs: sorted ranks per chain-length class (the matcher's hand-out order)
+  uint32_t qhead;
+  uint32_t ocnt[4];   // sorted ranks per chain-length class (the matcher's hand-out order)
   struct { uint32_t ji, job, L, Dl; uint64_t c, cstart, rec_at, dstart; } nx;   // the NEXT job's metadata, fetched while this one runs
   uint32_t pexit[NT / 64], pexit2[NT / 64], pconv[NT / 64];
-  uint8_t wtab[NT];   // dictionary jobs: per wavefront, lane that holds the r-th pending work rank of the wave's window
+  uint8_t wtab[WQ ? NT : 64];   // class B's dictionary jobs (no hand-out list): per wavefront, lane that holds the r-th pending work rank of the wave's window
 };
 
 constexpr int align16(int v) { return (v + 15) & ~15; }
+
+// Size classes of the match kernel by window T = dictionary + chunk (the table behind `struct Layout` says what each keeps in LDS).  The caps of
+// the two-per-CU classes are what 80 KiB of LDS hold (static_assert in Layout): FastCDC's chunk sizes peak just above the 8 KiB average
+// (18 / 14 / 11 / 9 % of the bytes in 8.0-8.5 / 8.5-9.0 / 9.0-9.5 / 9.5-10.0 KiB chunks), and every class is cheaper per byte than the next.
+#ifndef HMSE_TCAP_S
+#define HMSE_TCAP_S 10048
+#define HMSE_TCAP_S2 13952
+#define HMSE_TCAP_SG 17408
+#define HMSE_TCAP_SG2 22976
+#endif
+constexpr int NT_S = 1024, TCAP_S = HMSE_TCAP_S, TCAP_S2 = HMSE_TCAP_S2, TCAP_SG = HMSE_TCAP_SG, TCAP_SG2 = HMSE_TCAP_SG2;
+constexpr int NT_M = 1024, TCAP_SG3 = 32768;
+#ifndef HMSE_NT_B
+#define HMSE_NT_B 1024
+#endif
+constexpr int NT_B = HMSE_NT_B, TCAP_B = 65536, LCAP_B = 32768;
 
 // LDS carve.  LDSM: every per-position array lives in LDS (size classes T <= TCAP);
 // !LDSM (rare big jobs): S / jump / match arrays live in a per-workgroup global scratch.
@@ -150,7 +162,7 @@ struct Layout {
   static constexpr int MARK_OFF = CUR_OFF + CUR_SZ;
   static constexpr int MARK_SZ = align16(LCAP / 8 + 16);
   static constexpr int SMALL_OFF = MARK_OFF + MARK_SZ;
-  static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT>));
+  static constexpr int SMALL_SZ = align16((int)sizeof(Small<NT, !LDSM>));
   static constexpr int A_OFF = SMALL_OFF + SMALL_SZ;    // LDSM: u16 S[T] -> u16 jump[L+1] -> out image; !LDSM: out image
   static constexpr int A_SZ = LDSM ? align16(2 * TCAP + 80) : align16(LCAP + 80);
   static constexpr int MD_OFF = A_OFF + A_SZ;           // LDSM: u16 mdist[L]
@@ -161,6 +173,7 @@ struct Layout {
   static constexpr int K_SZ = (LDSM && !NOK) ? align16(TCAP + 16) : 0;
   static constexpr int TOTAL = K_OFF + K_SZ;
   static_assert(TOTAL <= 160 * 1024, "one workgroup's LDS image must fit the CU's 160 KiB");
+  static_assert(!(LDSM && TCAP <= TCAP_SG2) || TOTAL <= 80 * 1024, "classes S .. SG2 run two workgroups per CU");
   static_assert(sizeof(HuffL) + sizeof(HuffD) <= CUR_SZ, "Huffman scratch must fit the cursor table");
 };
 
@@ -408,14 +421,14 @@ struct Scratch {
 // DICT: the instantiation that runs the dictionary jobs of its class (chunk + base chunk; yields the DELTA and the FULL
 // record).  Plain jobs run the DICT = false instantiation, which carries none of the snapshot code or its registers.
 template <int NT, int TCAP, int LCAP_, bool LDSM, bool MDG = false, bool MLG = false, bool NOK = false, bool DICT = false>
-__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <= 16000 || NOK) ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
+__global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= TCAP_SG2 ? 8 : 4) : 2)) void l1_deflate_kernel(Args a) {
   using LY = Layout<NT, TCAP, LCAP_, LDSM, MDG, MLG, NOK>;
   constexpr int LCAP = LY::LCAP;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const W = smem + LY::W_OFF;
   uint32_t* const cur = (uint32_t*)(smem + LY::CUR_OFF);
   uint32_t* const mark = (uint32_t*)(smem + LY::MARK_OFF);
-  Small<NT>& sm = *(Small<NT>*)(smem + LY::SMALL_OFF);
+  Small<NT, !LDSM>& sm = *(Small<NT, !LDSM>*)(smem + LY::SMALL_OFF);
   Scratch* const sc = LDSM ? nullptr : (Scratch*)(a.scratch + (size_t)blockIdx.x * a.scratch_stride);
   uint16_t* const mdist_g = (uint16_t*)(a.scratch2 + (size_t)blockIdx.x * a.scratch2_stride);  // used by S2/SG/B only
   uint16_t* const S = LDSM ? (uint16_t*)(smem + LY::A_OFF) : sc->S;
@@ -539,7 +552,6 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
     for (uint32_t i = t; i < NBK / 2; i += NT) cur[i] = 0;
     for (uint32_t i = t; i < 288; i += NT) sm.lf[i] = 0;
     if (t < 32) sm.df[t] = 0;
-    if (t < 20) sm.cf[t] = 0;
     if (t == 0) sm.qhead = 0;
     if (t < 4) sm.ocnt[t] = 0;
     // (16 bytes per store: both arrays start on a 16-byte boundary and hold LCAP = a multiple of 16 bytes)
@@ -1025,7 +1037,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
           // (near-duplicate chunks) spend most of their trips here, a full-length match is 258 bytes
           // (64 bytes where the class runs one workgroup per CU and so may use 128 VGPRs: SG3 and B, the classes of the
           // largest dictionary jobs)
-          if constexpr (!LDSM || TCAP > 21504) {
+          if constexpr (!LDSM || TCAP > TCAP_SG2) {
             uint64_t da[8], db[8];
             ldNa<8>(W, q + ml, da); ldNa<8>(W, p + ml, db);
             uint32_t adv = 64;
@@ -1281,7 +1293,7 @@ __global__ __launch_bounds__(NT, (LDSM ? (NT == 1024 && TCAP <= 21504 && (TCAP <
   }
 #undef PF_STAGE
 #ifdef HMSE_DFL_STAMPS
-  if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= 9216 ? 0 : TCAP <= 16000 ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
+  if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_dfl_stamps[(TCAP <= TCAP_S ? 0 : TCAP <= TCAP_SG ? 1 : 2) + (DICT ? 3 : 0)][i], stamp_acc[i]);
 #endif
 }
 
@@ -1634,17 +1646,16 @@ __global__ __launch_bounds__(128, 8) void l1_encode_kernel(Args a, const bool fo
 #undef ESTAMP
 }
 
-// Size classes of the match kernel (window T = dictionary + chunk).  Per-position arrays in LDS:
-//   S  : T <= 9216   window, sorted ranks, byte-4 filter, match lengths and distances   (79 KiB, two per CU)
-//   S2 : T <= 12288  as S, match distances in a per-workgroup global array              (76 KiB, two per CU)
-//   SG : T <= 16000  as S2, match lengths there too                                     (79 KiB, two per CU)
-//   SG2: T <= 21504  as SG, without the byte-4 filter array                             (80 KiB, two per CU)
-//   SG3: T <= 32768  as SG2                                                             (115 KiB, one per CU)
-//   B  : T <= 65536  window in LDS, everything else in a per-workgroup global scratch (dictionary jobs only)
-// Two-per-CU classes run 1024 threads capped at 64 VGPRs: the CU's full 32 waves.
-constexpr int NT_S = 1024, TCAP_S = 9216, TCAP_S2 = 12288, TCAP_SG = 16000, TCAP_SG2 = 21504;
-constexpr int NT_M = 1024, TCAP_SG3 = 32768;
-constexpr int NT_B = 512, TCAP_B = 65536, LCAP_B = 32768;
+// Size classes of the match kernel (window T = dictionary + chunk; caps: HMSE_TCAP_* at the top).  Per-position arrays in LDS:
+//   S  : T <= 10048  window, sorted ranks, byte-4 filter, match lengths and distances   (80 KiB, two per CU)
+//   S2 : T <= 13952  as S, match distances in a per-workgroup global array              (80 KiB, two per CU)
+//   SG : T <= 17408  as S2, match lengths there too                                     (80 KiB, two per CU)
+//   SG2: T <= 22976  as SG, without the byte-4 filter array                             (80 KiB, two per CU)
+//   SG3: T <= 32768  as SG2                                                             (112 KiB, one per CU)
+//   B  : T <= 65536  window in LDS, everything else in a per-workgroup global scratch (dictionary jobs only; 1024 threads, one per CU)
+// Two-per-CU classes run 1024 threads capped at 64 VGPRs: the CU's full 32 waves.  (Round 4: the caps were 9216 / 12288 / 16000 / 21504 with
+// the encode kernel's fields in `Small`; a plain job costs the same per byte in the class below, so the plain kernels did not move, but 3 ms of
+// dictionary jobs moved from the one-per-CU class SG3 to SG2.)
 constexpr int N_LIST = 17;      // plain jobs per class: lists 0 (S), 4 (S2), 5 (SG), 8 (SG2), 2 (SG3), 3 (B); dictionary jobs per class:
                                 // lists 9..14 (dict_list); encode-kernel lists by chunk length: 6 and 7 (FULL records), 15 and 16 (DELTA
                                 // records).  The dictionary jobs run FIRST: the chunks whose delta is no quick accept (rule 7) then join

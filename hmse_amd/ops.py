@@ -208,6 +208,11 @@ def deflate_ws_limit(device) -> int:
     return max(256 << 20, min(DEFLATE_WS_LIMIT, (free + cached) // 2))
 
 
+# windows T = dictionary + chunk of the match kernel's size classes S, S2, SG, SG2, SG3 (hmse_amd/csrc/l1_deflate.hip: HMSE_TCAP_*; above: class B) —
+# diagnostics only (bench.py's per-class algorithmic bytes, tools/): the library classifies on the device
+DEFLATE_CLASS_CAPS = (10048, 13952, 17408, 22976, 32768)
+
+
 def l1_deflate(data: torch.Tensor, cuts: torch.Tensor, cfg: IngestConfig, chunk_ids: torch.Tensor | None = None,
                base: torch.Tensor | None = None, base_is_chunk_id: bool = False, ws: torch.Tensor | None = None,
                ws_limit: int | None = None):

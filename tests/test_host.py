@@ -396,3 +396,15 @@ def test_isa_audit_finds_nothing_unpinned():
     imports = isa_audit.imported_hip_calls(lib)
     assert not [s for s in imports if "Async" in s or "Graph" in s], imports
     assert set(imports) <= set(pin["hip_imports_allowed"]), sorted(set(imports) - set(pin["hip_imports_allowed"]))
+
+
+def test_python_side_class_caps_are_the_kernel_source_s():
+    """bench.py and the tools price the match kernels' size classes with ops.DEFLATE_CLASS_CAPS; the kernel's own caps are the
+    HMSE_TCAP_* defaults of l1_deflate.hip (the device classifies): the two must not drift apart."""
+    import os
+    import re
+    from hmse_amd import ops
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hmse_amd", "csrc", "l1_deflate.hip")).read()
+    caps = tuple(int(re.search(r"#define %s (\d+)" % name, src).group(1)) for name in ("HMSE_TCAP_S", "HMSE_TCAP_S2", "HMSE_TCAP_SG", "HMSE_TCAP_SG2"))
+    sg3 = int(re.search(r"TCAP_SG3 = (\d+)", src).group(1))
+    assert caps + (sg3,) == tuple(ops.DEFLATE_CLASS_CAPS)

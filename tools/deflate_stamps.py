@@ -39,12 +39,13 @@ Tdelta = (lens + torch.clamp(lens[base.clamp(min=0)], max=32768))[hb]
 allT = torch.cat([Tfull, Tdelta]).cpu().numpy()
 allL = torch.cat([lens, lens[hb]]).cpu().numpy()
 import numpy as _np
-cls_ = _np.where(allT <= 9216, 0, _np.where(allT <= 12288, 1, _np.where(allT <= 16000, 2, _np.where(allT <= 21504, 3, _np.where(allT <= 32768, 4, 5)))))
+_c = ops.DEFLATE_CLASS_CAPS
+cls_ = _np.where(allT <= _c[0], 0, _np.where(allT <= _c[1], 1, _np.where(allT <= _c[2], 2, _np.where(allT <= _c[3], 3, _np.where(allT <= _c[4], 4, 5)))))
 for ci_, nm in enumerate(("S", "S2", "SG", "SG2", "SG3", "B")):
     m_ = cls_ == ci_
     print("class %-6s jobs %6d  window bytes %6.1f MB  chunk bytes %6.1f MB" % (nm, m_.sum(), allT[m_].sum() / 1e6, allL[m_].sum() / 1e6))
 print("deflate op ms", e0.elapsed_time(e1), "jobs", uniq.numel(), "+", int((base >= 0).sum()))
-for c, cn in enumerate(["plain S (T <= 9216)", "plain S2, SG (T <= 16000)", "plain SG2, SG3, B", "DICT S", "DICT S2, SG", "DICT SG2, SG3, B"]):
+for c, cn in enumerate([f"plain S (T <= {_c[0]})", f"plain S2, SG (T <= {_c[2]})", "plain SG2, SG3, B", "DICT S", "DICT S2, SG", "DICT SG2, SG3, B"]):
     row = buf[c * 24:(c + 1) * 24].astype(np.float64)
     occ = row[16:22].copy(); row = row[:16]
     trips, positions, jobs = row[13], row[14], row[15]

@@ -15,7 +15,7 @@ def work(buf):
     res = {k: np.zeros(8, np.uint64) for k in V}; pos = 0; nj = 0
     for i in range(len(cuts) - 1):
         ch = d[int(cuts[i]):int(cuts[i + 1])]
-        if ch.size > 9216: continue          # class S
+        if ch.size > 10048: continue          # class S
         pos += ch.size; nj += 1
         for k, (b, var, ct) in V.items(): L.study_sched(ch.ctypes.data, ch.size, 32, 16, b, var, ct, res[k].ctypes.data)
     return pos, nj, res
