@@ -85,8 +85,17 @@ __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
   return r;
 }
 
+#ifdef HMSE_DIAG
+__device__ unsigned long long g_mh_stamps[16];   // diagnostic build: thread 0's clocks per phase (tools/minhash_stamps.py)
+#define MH_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now__ = clock64(); mh_acc[i] += now__ - mh_last; mh_last = now__; } } while (0)
+#else
+#define MH_STAMP(i) do { } while (0)
+#endif
+
+// (launch bounds: 64 VGPRs, so that two 1024-thread workgroups share a CU — at 72 registers, which two experiments of round 4 reached, one
+// workgroup per CU runs and the kernel takes 15.9 instead of 11.2 ms at 2 GB)
 template <int NT, int V>
-__global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restrict__ data, uint64_t n,
+__global__ __launch_bounds__(NT, NT == 1024 ? 8 : 4) void l4_minhash_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                         const uint64_t* __restrict__ cuts,
                                                         const uint64_t* __restrict__ chunk_ids, uint64_t n_sel,
                                                         uint32_t seed_base, uint32_t* __restrict__ sig, const uint64_t* __restrict__ st,
@@ -98,6 +107,9 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
   if (st) { chunk_ids += st[SB_U_OLD]; sig += 128 * st[SB_U_OLD]; n_sel = st[SB_U_NEW]; }   // captured chain: this batch's stored chunks
   const uint64_t sel = sel0 + blockIdx.x;
   if (sel >= n_sel) return;
+#ifdef HMSE_DIAG
+  unsigned long long mh_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mh_last = clock64();
+#endif
   const uint32_t t = threadIdx.x, lane = lane_id(), w = t >> 6;
   const uint64_t c = chunk_ids ? chunk_ids[sel] : sel;
   const uint64_t start = cuts[c];
@@ -108,6 +120,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
   uint32_t* q = s_tab + w * PART;
   if (t < 128) { s_glob[t] = 0xFFFFFFFFu; s_min[t] = 0xFFFFFFFFu; }
   if (t == 0) { s_nun = 0; s_any = 0; }
+  MH_STAMP(0);   // prologue: the chunk's metadata
 
   for (uint64_t sub0 = 0; sub0 < nsh; sub0 += MH_SUB) {
     const uint32_t cnt = (uint32_t)((nsh - sub0) < (uint64_t)MH_SUB ? (nsh - sub0) : (uint64_t)MH_SUB);
@@ -120,6 +133,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       s_ins = memo.tab && __hip_atomic_load(memo.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < memo.cap;
     }
     __syncthreads();
+    MH_STAMP(1);   // clear + "room in the table?"
     const bool ins = s_ins != 0;
     // insert R of every shingle of this pass
     // Four consecutive shingles per lane from three ALIGNED, coalesced dword loads (round 4): a 4-byte load at a byte-granular address per
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       }
     }
     __syncthreads();
+    MH_STAMP(2);   // set inserts
     // in-place compaction of this wave's part (write index never passes the read index)
     uint32_t wr = 0;
     static_assert(PART % 256 == 0, "the compaction reads four 64-entry rows per round trip");
@@ -175,6 +190,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
         wr += (uint32_t)__builtin_popcountll(m);
       }
     }
+    MH_STAMP(3);   // compaction
     // ---- memo lookups: every distinct shingle of this wavefront's part; what the table cannot answer goes to the top of
     // the part (the todo list), which the tail loop below then streams instead of the whole part
     uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;   // this pass, this wavefront: minima over the computed shingles
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       if (lane == 0 && (memo.probe & 4u)) { atomicAdd(memo.count + 1, looked); atomicAdd(memo.count + 2, nt); atomicAdd(memo.count + 4, wr); }   // tools/minhash_memo_stats.py
 #endif
     }
+    MH_STAMP(4);   // look-ups
     // one computed shingle -> the table: which of its 128 hashes fall below TAU
     auto memo_insert = [&](uint32_t R, uint32_t a0, uint32_t a1) {
       const uint64_t b0 = __ballot(a0 < MH_TAU), b1 = __ballot(a1 < MH_TAU);
@@ -257,6 +274,10 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
       __builtin_amdgcn_wave_barrier();
     };
     // stream the todo list (without a table: the whole part) through the 2 seeds of this lane
+    // (Round 4, measured and rejected, both at 64 registers: POOLING the wavefronts' todo lists so that every wavefront streams an equal share —
+    // the barrier behind this loop waits 7-15 % of thread 0's clocks for the fullest part, tools/minhash_stamps.py — needs a barrier in front of
+    // the loop, which stops the early wavefronts' tails from running beside the late wavefronts' gathers: 11.4 -> 11.8 ms at 2 GB; the chunk's
+    // byte loads issued a group ahead, the first one in front of the clear: 11.2 against 11.1 — the CU's other workgroup already hides them.)
     if (V == 2) nt = 0;
     uint32_t hd = (4u - ((uint32_t)(tp - q) & 3u)) & 3u;      // entries in front of the first 16-byte boundary
     if (hd > nt) hd = nt;
@@ -289,9 +310,11 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
     }
     // ---- this pass's minima: computed (per wavefront) and looked up (s_min); seeds still at or above TAU where a table
     // was consulted are re-evaluated over every distinct shingle of the pass
+    MH_STAMP(5);   // tail: the shingles the table could not answer
     s_sig[w][lane] = m0;
     s_sig[w][lane + 64] = m1;
     __syncthreads();
+    MH_STAMP(6);   // barrier behind the tail (the slowest wavefront)
     if (t < 128) {
       uint32_t v = s_min[t];
 #pragma unroll
@@ -321,9 +344,22 @@ __global__ __launch_bounds__(NT) void l4_minhash_kernel(const uint8_t* __restric
     if (t < 128) { s_glob[t] = min(s_glob[t], s_pass[t]); s_min[t] = 0xFFFFFFFFu; }
     if (t == 0) { s_nun = 0; s_any = 0; }
     __syncthreads();
+    MH_STAMP(7);   // combine + re-evaluation
   }
   if (t < 128) sig[sel * 128 + t] = s_glob[t];
+#ifdef HMSE_DIAG
+  MH_STAMP(8);
+  if (threadIdx.x == 0) { for (int i = 0; i < 9; i++) atomicAdd(&g_mh_stamps[i], mh_acc[i]); atomicAdd(&g_mh_stamps[15], 1ull); }
+#endif
 }
+
+#ifdef HMSE_DIAG
+extern "C" int hmse_debug_minhash_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mh_stamps), sizeof(g_mh_stamps)) != hipSuccess) return HMSE_EHIP;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mh_stamps), z, sizeof z) != hipSuccess) return HMSE_EHIP; }
+  return HMSE_OK;
+}
+#endif
 
 // workspace: [0, 256) header (entry count), then the memo table
 size_t hmse_l4_minhash_workspace_bytes_impl(uint64_t) { return 256 + ((size_t)8 << MH_MEMO_BITS); }
