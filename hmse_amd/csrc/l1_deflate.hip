@@ -1784,21 +1784,22 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint64_t* __restrict_
   // One chunk per WAVEFRONT (round 4; one per 256-thread workgroup before): a chunk's copy is ~2.7 KiB behind a chain of three dependent
   // metadata loads, so the kernel's time was that chain's latency over the chunks in flight per CU (8); now 32.
   if (n_dev) n_sel = *n_dev;
-  const uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (k >= n_sel) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t obase = out_base_dev ? *out_base_dev : 0ull;   // captured chain: streams are appended behind the earlier batches'
-  const uint64_t c = chunk_ids ? chunk_ids[k] : k;
-  const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
-  if (len > 32768u) return;
-  const uint8_t* src = recs + rec_off[k] + rec_slot_off(len, (kind && kind[k] == HMSE_KIND_DELTA) ? 1u : 0u);
-  const uint64_t o0 = out_off[k], o1 = out_off[k + 1];
-  if (obase + o1 > out_cap) { if (lane == 0) atomicOr(status, 1u); return; }
-  const uint32_t nb = (uint32_t)(o1 - o0);
-  uint8_t* dst = out + obase + o0;
-  for (uint32_t i = lane * 16; i < nb; i += 64u * 16u) {
-    if (i + 16 <= nb) { const uint4 v = *(const uint4*)(src + i); __builtin_memcpy(dst + i, &v, 16); }
-    else for (uint32_t b = i; b < nb; b++) dst[b] = src[b];
+  // (a wavefront takes every (4 x gridDim.x)-th chunk: the captured chain's grid is sized for the chunks a batch CAN hold)
+  for (uint64_t k = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); k < n_sel; k += (uint64_t)gridDim.x * 4u) {
+    const uint64_t c = chunk_ids ? chunk_ids[k] : k;
+    const uint32_t len = (uint32_t)(cuts[c + 1] - cuts[c]);
+    if (len > 32768u) continue;
+    const uint8_t* src = recs + rec_off[k] + rec_slot_off(len, (kind && kind[k] == HMSE_KIND_DELTA) ? 1u : 0u);
+    const uint64_t o0 = out_off[k], o1 = out_off[k + 1];
+    if (obase + o1 > out_cap) { if (lane == 0) atomicOr(status, 1u); continue; }
+    const uint32_t nb = (uint32_t)(o1 - o0);
+    uint8_t* dst = out + obase + o0;
+    for (uint32_t i = lane * 16; i < nb; i += 64u * 16u) {
+      if (i + 16 <= nb) { const uint4 v = *(const uint4*)(src + i); __builtin_memcpy(dst + i, &v, 16); }
+      else for (uint32_t b = i; b < nb; b++) dst[b] = src[b];
+    }
   }
 }
 
@@ -2042,7 +2043,7 @@ static int deflate_impl(const uint8_t* data, uint64_t n, const uint64_t* cuts, c
                                                         cfg->delta_max_ratio_pct, w.final_len, kind, status, n_dev);
   HMSE_LAUNCH_CHECK();
   if (exclusive_scan_u64(w.final_len, n_sel, out_off, w.bsum, out_off + n_sel, stream, n_dev) != HMSE_OK) return HMSE_EHIP;
-  gather_kernel<<<dim3((uint32_t)((n_sel + 3) / 4)), dim3(256), 0, stream>>>(cuts, chunk_ids, n_sel, w.rec_off, w.recs, kind, out_off, out,
+  gather_kernel<<<dim3((uint32_t)((n_sel + 3) / 4 < 16384 ? (n_sel + 3) / 4 : 16384)), dim3(256), 0, stream>>>(cuts, chunk_ids, n_sel, w.rec_off, w.recs, kind, out_off, out,
                                                                 out_cap, status, n_dev, out_base_dev);
   HMSE_LAUNCH_CHECK();
   return HMSE_OK;
